@@ -1,0 +1,231 @@
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF and pin the oracle restatement to it.
+
+Run in the build container only (needs /root/reference):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+It puts oracle/stubs (stand-ins for the absent torchvision / rising / pytorch_lightning packages)
+and /root/reference on sys.path, imports the reference's models/unetvgg.py, models/unetplusplus.py,
+loss/dice.py and loss/focal.py, runs them on hash-initialised weights and synthetic batches, and
+
+ 1. asserts that oracle/ref_models.py and oracle/ref_losses.py reproduce every output BIT FOR BIT
+    (same ATen calls in the same order), writing the verdict to tests/golden/oracle_pin.json;
+ 2. stores the reference outputs as small fixtures that the CPU and GPU tests compare against.
+
+Nothing of the reference's source travels: fixtures are inputs' recipes (tags for the hash
+initialiser) and output arrays only.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(HERE, "stubs"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from oracle import ref_losses as RL  # noqa: E402
+from oracle import ref_models as RM  # noqa: E402
+
+torch.set_num_threads(8)
+torch.manual_seed(20)
+
+
+def import_reference():
+    import importlib
+    mods = {}
+    for name in ("models.unetvgg", "models.unetplusplus", "loss.dice", "loss.focal"):
+        mods[name] = importlib.import_module(name)
+        assert mods[name].__file__.startswith(REF), mods[name].__file__
+    return mods
+
+
+def bits_equal(a, b):
+    return a.shape == b.shape and a.dtype == b.dtype and torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------ losses
+def loss_cases():
+    """(name, C, N, side, kwargs) -- labels/logits come from hash tags so tests can rebuild them."""
+    return [
+        ("c4_n2_s8", 4, 2, 8, {}),
+        ("c3_n1_s8", 3, 1, 8, {}),
+        ("c4_n4_s64", 4, 4, 64, {}),
+        ("c3_n4_s64", 3, 4, 64, {}),
+        ("c4_n4_s64_allbg", 4, 4, 64, {"allbg": True}),
+        ("c4_n3_s16_allchan", 4, 3, 16, {"is_all_chann": True}),
+        ("c4_n2_s16_nosft", 4, 2, 16, {"no_sft": True}),
+        ("c4_n2_s16_g0", 4, 2, 16, {"gamma": 0.0}),
+        ("c4_n2_s16_g1p5", 4, 2, 16, {"gamma": 1.5}),
+        ("c4_n2_s16_alpha", 4, 2, 16, {"alpha": [0.2, 1.0, 2.0, 0.5]}),
+        ("c4_n2_s16_sum", 4, 2, 16, {"reduction": "sum"}),
+        ("c4_n1_s384", 4, 1, 384, {}),
+    ]
+
+
+def make_loss_inputs(name, C, N, side, kw):
+    logits = RM.hash_uniform(f"loss:{name}:z", (N, C, side, side), -3.0, 3.0)
+    _, labels = RM.synthetic_batch(N, side, C, tag=f"loss:{name}")
+    if kw.get("allbg"):
+        labels = torch.zeros_like(labels)
+    return logits, labels
+
+
+def golden_losses(ref, pin):
+    out = {}
+    dice_ref, focal_ref = ref["loss.dice"], ref["loss.focal"]
+    for name, C, N, side, kw in loss_cases():
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        dkw = {k: kw[k] for k in ("no_sft", "is_all_chann") if k in kw}
+        fkw = {k: kw[k] for k in ("gamma", "reduction") if k in kw}
+        if "alpha" in kw:
+            fkw["alpha"] = torch.tensor(kw["alpha"])
+        res = {}
+        for tag, fn_ref, fn_or, k in (("dice", dice_ref.dice_loss_sq, RL.dice_loss_sq, dkw),
+                                      ("focal", focal_ref.focal_loss_with_logits, RL.focal_loss_with_logits, fkw)):
+            zin = torch.softmax(z, 1) if (tag == "dice" and kw.get("no_sft")) else z
+            a = zin.clone().requires_grad_(True)
+            la = fn_ref(a, t, **k)
+            la.sum().backward()
+            b = zin.clone().requires_grad_(True)
+            lb = fn_or(b, t, **k)
+            lb.sum().backward()
+            pin[f"loss/{name}/{tag}"] = bool(bits_equal(la.detach(), lb.detach()) and bits_equal(a.grad, b.grad))
+            res[tag] = la.detach().numpy()
+            g = a.grad
+            res[tag + "_grad"] = g.numpy() if side <= 64 else g[..., ::16, ::16].contiguous().numpy()
+            res[tag + "_grad_sum"] = np.float64(g.double().sum().item())
+            res[tag + "_grad_abs"] = np.float64(g.double().abs().sum().item())
+        # metric (non-differentiable)
+        m_ref = dice_ref.dice_coefficient(z, t)
+        m_or = RL.dice_coefficient(z, t)
+        pin[f"loss/{name}/metric"] = bool(bits_equal(m_ref, m_or))
+        res["metric"] = m_ref.numpy()
+        res["metric_list"] = dice_ref.dice_coefficient(z, t, is_list_bat=True).numpy()
+        for k2, v in res.items():
+            out[f"{name}/{k2}"] = v
+    # 4-D one-hot target path (dice.py:53-54) and the closed-form known answers
+    z = torch.zeros(2, 4, 8, 8)
+    t = torch.zeros(2, 8, 8, dtype=torch.long)
+    t[:, :4, :] = 1
+    t[0, 4:, :4] = 2
+    out["ka/zero_logits_dice"] = dice_ref.dice_loss_sq(z, t).numpy()
+    out["ka/zero_logits_focal"] = focal_ref.focal_loss_with_logits(z, t).numpy()
+    t2 = t.clone()
+    t2[1] = 0
+    out["ka/zero_logits_dice_img1bg"] = dice_ref.dice_loss_sq(z, t2).numpy()
+    out["ka/allbg_dice"] = dice_ref.dice_loss_sq(z, torch.zeros_like(t)).numpy()
+    out["ka/allbg_metric"] = dice_ref.dice_coefficient(z, torch.zeros_like(t)).numpy()
+    hot = torch.zeros(2, 4, 8, 8).scatter(1, t.unsqueeze(1), 1)
+    zz = RM.hash_uniform("loss:onehot4d", (2, 4, 8, 8), -2, 2)
+    out["ka/onehot4d_dice"] = dice_ref.dice_loss_sq(zz, hot).numpy()
+    pin["loss/onehot4d"] = bool(bits_equal(dice_ref.dice_loss_sq(zz, hot), RL.dice_loss_sq(zz, hot)))
+    np.savez_compressed(os.path.join(GOLD, "losses.npz"), **out)
+
+
+# ------------------------------------------------------------------------------------ models
+def model_cases(ref):
+    uv, up = ref["models.unetvgg"], ref["models.unetplusplus"]
+    return [
+        ("unetvgg_c4", lambda: uv.UNetVgg(out_classes=4), lambda: RM.RefUNetVgg(out_classes=4), 3),
+        ("unetvgg_c3", lambda: uv.UNetVgg(out_classes=3), lambda: RM.RefUNetVgg(out_classes=3), 3),
+        ("unetvgg_c4_convtrans", lambda: uv.UNetVgg(out_classes=4, if_convtrans=True),
+         lambda: RM.RefUNetVgg(out_classes=4, if_convtrans=True), 3),
+        ("unetvgginout_c4", lambda: uv.UNetVggInOut(in_classes=1, out_classes=4),
+         lambda: RM.RefUNetVgg(out_classes=4, in_classes=1), 1),
+        ("nestedunet_c4", lambda: up.Nested_UNet(in_ch=1, out_ch=4), lambda: RM.RefNestedUNet(in_ch=1, out_ch=4), 1),
+    ]
+
+
+def run_step(model, x, t, losses):
+    model.train()
+    model.zero_grad()
+    logits = model(x)
+    loss = sum(fn(logits, t) for fn in losses)
+    loss.backward()
+    return logits.detach(), loss.detach()
+
+
+def golden_models(ref, pin):
+    dice_ref, focal_ref = ref["loss.dice"], ref["loss.focal"]
+    out, keys = {}, {}
+    for name, mk_ref, mk_or, in_ch in model_cases(ref):
+        n_cls = 3 if name.endswith("c3") else 4
+        x, t = RM.synthetic_batch(2, 64, n_cls, in_ch=in_ch, tag=f"model:{name}")
+        m_ref = RM.hash_init_(mk_ref())
+        m_or = RM.hash_init_(mk_or())
+        assert list(m_ref.state_dict().keys()) == list(m_or.state_dict().keys()), name
+        for (ka, va), (kb, vb) in zip(m_ref.state_dict().items(), m_or.state_dict().items()):
+            assert va.shape == vb.shape and torch.equal(va, vb), (name, ka)
+        keys[name] = {k: list(v.shape) for k, v in m_ref.state_dict().items()}
+        la, lossa = run_step(m_ref, x, t, [dice_ref.dice_loss_sq, focal_ref.focal_loss_with_logits])
+        lb, lossb = run_step(m_or, x, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
+        same = bits_equal(la, lb) and bits_equal(lossa, lossb)
+        for (ka, pa), (_, pb) in zip(m_ref.named_parameters(), m_or.named_parameters()):
+            same = same and bits_equal(pa.grad, pb.grad)
+        for (ka, ba), (_, bb) in zip(m_ref.named_buffers(), m_or.named_buffers()):
+            same = same and bits_equal(ba, bb)
+        pin[f"model/{name}"] = bool(same)
+        out[f"{name}/logits"] = la.numpy()
+        out[f"{name}/loss"] = lossa.numpy()
+        out[f"{name}/mask"] = la.argmax(1).to(torch.uint8).numpy()
+        top2 = la.topk(2, dim=1).values
+        out[f"{name}/near_tie_1e-3"] = np.int64(((top2[:, 0] - top2[:, 1]) < 1e-3).sum().item())
+        for k, p in m_ref.named_parameters():
+            g = p.grad.flatten()
+            out[f"{name}/grad_norm/{k}"] = np.float64(g.double().norm().item())
+            out[f"{name}/grad_head/{k}"] = g[:16].numpy().copy()
+        for k, b in m_ref.named_buffers():
+            if not k.endswith("num_batches_tracked"):
+                out[f"{name}/buf/{k}"] = b.numpy().copy()
+        # eval-mode logits after the step (running statistics path)
+        m_ref.eval()
+        with torch.no_grad():
+            le = m_ref(x)
+        out[f"{name}/eval_logits_sub"] = le[..., ::4, ::4].contiguous().numpy()
+        out[f"{name}/eval_mask"] = le.argmax(1).to(torch.uint8).numpy()
+    # one full-size slice: UNetVgg 384x384, N=1, C=4
+    uv = ref["models.unetvgg"]
+    x, t = RM.synthetic_batch(1, 384, 4, in_ch=3, tag="model:unetvgg384")
+    m_ref = RM.hash_init_(uv.UNetVgg(out_classes=4))
+    m_or = RM.hash_init_(RM.RefUNetVgg(out_classes=4))
+    la, lossa = run_step(m_ref, x, t, [dice_ref.dice_loss_sq, focal_ref.focal_loss_with_logits])
+    lb, lossb = run_step(m_or, x, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
+    pin["model/unetvgg384"] = bool(bits_equal(la, lb) and bits_equal(lossa, lossb))
+    out["unetvgg384/mask_packed"] = np.packbits(la.argmax(1).to(torch.uint8).numpy().astype(np.uint8), bitorder="little")  # 2 bits would do; keep simple
+    out["unetvgg384/mask"] = la.argmax(1).to(torch.uint8).numpy()
+    out["unetvgg384/logits_sub"] = la[..., ::8, ::8].contiguous().numpy()
+    out["unetvgg384/loss"] = lossa.numpy()
+    top2 = la.topk(2, dim=1).values
+    out["unetvgg384/near_tie_1e-3"] = np.int64(((top2[:, 0] - top2[:, 1]) < 1e-3).sum().item())
+    for k, p in m_ref.named_parameters():
+        out[f"unetvgg384/grad_norm/{k}"] = np.float64(p.grad.double().norm().item())
+    del out["unetvgg384/mask_packed"]
+    np.savez_compressed(os.path.join(GOLD, "models.npz"), **out)
+    with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    ref = import_reference()
+    pin = {}
+    golden_losses(ref, pin)
+    golden_models(ref, pin)
+    verdict = {"torch": torch.__version__, "numpy": np.__version__, "all_bitwise_equal": all(pin.values()), "checks": pin}
+    with open(os.path.join(GOLD, "oracle_pin.json"), "w") as f:
+        json.dump(verdict, f, indent=1, sort_keys=True)
+    print(json.dumps(verdict, indent=1, sort_keys=True))
+    if not verdict["all_bitwise_equal"]:
+        raise SystemExit("oracle restatement differs from the reference")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,121 @@
+"""CPU oracle for the pixel-mask losses.  TEST INFRASTRUCTURE ONLY.
+
+Pure-torch restatement of the arithmetic of the reference's losses, written from the formulas the
+reference code evaluates (not from its text):
+
+* soft squared Dice        -- /root/reference/loss/dice.py:25-87  (loss = 1 - coefficient, :22-23)
+* arg-max Dice metric      -- /root/reference/loss/dice.py:89-184
+* multi-class focal loss   -- /root/reference/loss/focal.py:32-75, 108-137
+
+Pinned by `oracle/make_golden.py`, which imports the reference itself in the build container and
+checks these functions against it bit for bit; the recorded outputs live in tests/golden/.
+Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import this module.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _one_hot(labels, n_classes, dtype=torch.float32):
+    """[N,H,W] integer labels -> [N,C,H,W] one-hot; H must equal W (dice.py:48 views with shape[2] twice)."""
+    n, side = labels.shape[0], labels.shape[2]
+    idx = labels.view(n, 1, side, side)
+    return torch.zeros(n, n_classes, side, side, dtype=dtype, device=labels.device).scatter(1, idx, 1)
+
+
+def _fg_images(act):
+    """Indices of batch items that contain any non-zero label (dice.py:82)."""
+    return torch.unique(torch.nonzero(act, as_tuple=True)[0])
+
+
+def _average_over_fg(dice, act, all_channels, guard_single_channel):
+    """Drop channel 0 unless asked, then average over images that have foreground (dice.py:74-86)."""
+    n_ch = dice.shape[1]
+    kept = dice if (all_channels or n_ch == 1) else dice[:, 1:]
+    per_img = kept.shape[1]
+    div = kept.numel()
+    sel = _fg_images(act)
+    if len(sel) and (n_ch > 1 or not guard_single_channel):
+        div = len(sel) * per_img
+    return kept[sel].sum() / div, kept
+
+
+def dice_coefficient_sq(probs, act, ignore_onlybg=False, no_sft=False, is_all_chann=False):
+    hot = _one_hot(act, probs.shape[1]) if act.dim() != 4 else act
+    p = probs if no_sft else torch.softmax(probs, dim=1)
+    inter = (p * hot).flatten(2).sum(2)
+    psq = (p * p).flatten(2).sum(2)
+    gsq = (hot * hot).flatten(2).sum(2)
+    dice = (2 * inter + 1) / (psq + gsq + 1)
+    coeff, _ = _average_over_fg(dice, act, is_all_chann, guard_single_channel=True)
+    return coeff
+
+
+def dice_loss_sq(pred, act, no_sft=False, is_all_chann=False):
+    return 1 - dice_coefficient_sq(pred, act, no_sft=no_sft, is_all_chann=is_all_chann)
+
+
+def dice_coefficient(probs, act, is_list_bat=False, nosft=False, channelcnt=None, is_all_chann=False):
+    if act.dim() != 4:
+        if not channelcnt:
+            channelcnt = probs.shape[-3]
+        hot = _one_hot(act, channelcnt)
+    else:
+        hot = act
+    p = probs if nosft else torch.softmax(probs, dim=1)
+    if p.dim() != 3:
+        p = torch.argmax(p, dim=1)
+    p = p.unsqueeze(1)
+    phot = torch.zeros(p.shape[0], channelcnt, *p.shape[-2:], device=p.device).scatter(1, p.long(), 1)
+    inter = (phot * hot).flatten(2).sum(2)
+    dice = (2 * inter + 1) / (phot.flatten(2).sum(2) + hot.flatten(2).sum(2) + 1)
+    coeff, kept = _average_over_fg(dice, act, is_all_chann, guard_single_channel=False)
+    return kept if is_list_bat else coeff
+
+
+def focal_loss_with_logits(p, t, gamma=2., alpha=None, reduction='elementwise_mean'):
+    ce = F.cross_entropy(p, t, weight=alpha, reduction='none')
+    q = F.softmax(p, dim=1)
+    hot = torch.zeros(t.shape[0], p.shape[1], *t.shape[1:], dtype=t.dtype, device=t.device).scatter_(1, t.unsqueeze(1), 1)
+    w = 1 - torch.where(hot == 1., q, 1 - q)
+    w.pow_(gamma)
+    out = w * 1. * ce.unsqueeze(1)
+    if reduction == 'elementwise_mean':
+        return out.mean()
+    if reduction == 'none':
+        return out
+    if reduction == 'sum':
+        return out.sum()
+    raise ValueError('Reduction parameter unknown.')
+
+
+def dice_focal_closed_form_grad(logits, labels, gamma=2.0, w_dice=1.0, w_focal=1.0):
+    """d(w_dice*dice_loss_sq + w_focal*focal)/dlogits from the closed forms the HIP backward kernel
+    implements; double precision, used to cross-check autograd and the kernel."""
+    z = logits.double()
+    n, c, h, w = z.shape
+    p = torch.softmax(z, 1)
+    g = _one_hot(labels, c, dtype=torch.float64)
+    A = (p * g).flatten(2).sum(2)
+    B = (p * p).flatten(2).sum(2)
+    G = g.flatten(2).sum(2)
+    den = B + G + 1
+    sel = (labels.flatten(1) != 0).any(1)
+    nsel = int(sel.sum())
+    u = torch.zeros_like(p)
+    if nsel and c > 1:
+        div = nsel * (c - 1)
+        coef = -(2 * g * den[:, :, None, None] - 2 * p * (2 * A + 1)[:, :, None, None]) / (den * den)[:, :, None, None] / div
+        coef[:, 0] = 0
+        coef[~sel] = 0
+        u = coef
+    gd = p * (u - (u * p).sum(1, keepdim=True))
+    logp = torch.log_softmax(z, 1)
+    ce = -(logp * g).sum(1, keepdim=True)
+    pt = (p * g).sum(1, keepdim=True)
+    S = (1 - pt) ** gamma + ((p ** gamma) * (1 - g)).sum(1, keepdim=True)
+    if gamma == 0:
+        v = -g * S / pt
+    else:
+        v = torch.where(g == 1, -S / pt - ce * gamma * (1 - pt) ** (gamma - 1), ce * gamma * p ** (gamma - 1))
+    gf = p * (v - (v * p).sum(1, keepdim=True)) / (n * c * h * w)
+    return w_dice * gd + w_focal * gf

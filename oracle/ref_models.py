@@ -1,0 +1,184 @@
+"""CPU oracle for the segmentation networks.  TEST INFRASTRUCTURE ONLY.
+
+Plain `torch.nn` restatement of the two graded networks with the reference's state_dict layout:
+
+* VGG16-BN encoder + five-stage decoder -- /root/reference/models/unetvgg.py:6-41 (decoder block),
+  :52-105 (UNetVgg), :158-213 (UNetVggInOut)
+* nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
+
+Pinned by `oracle/make_golden.py` (bitwise equality with the imported reference in the build
+container).  Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import it.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+# (first VGG feature index, conv widths) of the five encoder stages; a stage after the first opens
+# with the max-pool that sits at `first` (unetvgg.py:72-76 slice the torchvision feature list).
+_STAGES = [(0, [64, 64]), (6, [128, 128]), (13, [256, 256, 256]), (23, [512, 512, 512]), (33, [512, 512, 512])]
+
+
+def _encoder_stage(first, c_in, widths):
+    mods, idx = OrderedDict(), first
+    if first:
+        mods[str(idx)] = nn.MaxPool2d(2, 2)
+        idx += 1
+    for wdt in widths:
+        mods[str(idx)] = nn.Conv2d(c_in, wdt, 3, padding=1)
+        mods[str(idx + 1)] = nn.BatchNorm2d(wdt)
+        mods[str(idx + 2)] = nn.ReLU(inplace=True)
+        c_in, idx = wdt, idx + 3
+    return nn.Sequential(mods)
+
+
+def decoder_block(c_in, c_mid, c_out, if_convtrans=False, noupsam=False, upsc=2):
+    head = [nn.Conv2d(c_in, c_mid, 3, padding=1), nn.ReLU(inplace=True)]
+    if noupsam:
+        tail = [nn.Conv2d(c_mid, c_out, 3, padding=1, bias=False), nn.InstanceNorm2d(c_out)]
+    elif if_convtrans:
+        tail = [nn.ConvTranspose2d(c_mid, c_out, kernel_size=4, stride=2, padding=1)]
+    else:
+        tail = [nn.Conv2d(c_mid, c_out, 3, padding=1, bias=False), nn.InstanceNorm2d(c_out),
+                nn.Upsample(scale_factor=upsc, mode='bilinear', align_corners=False)]
+    return nn.Sequential(*head, *tail, nn.ReLU(inplace=True))
+
+
+class RefUNetVgg(nn.Module):
+    def __init__(self, out_classes=3, if_convtrans=False, in_classes=None, patch_train=False):
+        super().__init__()
+        self.patch_train = patch_train
+        if in_classes is not None:          # UNetVggInOut: extra conv in front, bilinear decoder only
+            self.conv0 = nn.Conv2d(in_classes, 3, 3, padding=1)
+        c = 3
+        for k, (first, widths) in enumerate(_STAGES):
+            setattr(self, f"conv{k + 1}", _encoder_stage(first, c, widths))
+            c = widths[-1]
+        ct = if_convtrans
+        self.center = nn.Sequential(nn.MaxPool2d(2, 2), decoder_block(512, 512, 256, ct))
+        self.dec5 = decoder_block(768, 512, 256, ct)
+        self.dec4 = decoder_block(768, 512, 256, ct)
+        self.dec3 = decoder_block(512, 256, 64, ct)
+        self.dec2 = decoder_block(192, 128, 32, ct)
+        self.dec1 = nn.Sequential(nn.Conv2d(96, 32, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(32, out_classes, 1)
+
+    def forward(self, x):
+        if hasattr(self, "conv0"):
+            x = self.conv0(x)
+        skips = []
+        for k in range(1, 6):
+            x = getattr(self, f"conv{k}")(x)
+            skips.append(x)
+        x = self.center(x)
+        for k in range(5, 0, -1):
+            x = getattr(self, f"dec{k}")(torch.cat([x, skips[k - 1]], 1))
+        return self.final(x)
+
+
+class RefDoubleConv(nn.Module):
+    def __init__(self, c_in, c_mid, c_out):
+        super().__init__()
+        self.activation = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(c_in, c_mid, 3, padding=1, bias=True)
+        self.bn1 = nn.BatchNorm2d(c_mid)
+        self.conv2 = nn.Conv2d(c_mid, c_out, 3, padding=1, bias=True)
+        self.bn2 = nn.BatchNorm2d(c_out)
+
+    def forward(self, x):
+        x = self.activation(self.bn1(self.conv1(x)))
+        return self.activation(self.bn2(self.conv2(x)))
+
+
+class RefNestedUNet(nn.Module):
+    def __init__(self, in_ch=1, out_ch=3):
+        super().__init__()
+        f = [64, 128, 256, 512, 1024]
+        self.pool = nn.MaxPool2d(2, 2)
+        self.Up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        for i in range(5):                                   # backbone column j = 0
+            setattr(self, f"conv{i}_0", RefDoubleConv(in_ch if i == 0 else f[i - 1], f[i], f[i]))
+        for j in range(1, 5):                                # nested columns
+            for i in range(5 - j):
+                setattr(self, f"conv{i}_{j}", RefDoubleConv(f[i] * j + f[i + 1], f[i], f[i]))
+        self.final = nn.Conv2d(f[0], out_ch, 1)
+
+    def forward(self, x):
+        node = {}
+        for i in range(5):
+            node[i, 0] = getattr(self, f"conv{i}_0")(x if i == 0 else self.pool(node[i - 1, 0]))
+            # every anti-diagonal i+j = const is completed as soon as node (i,0) exists
+            for j in range(1, i + 1):
+                r = i - j
+                parts = [node[r, k] for k in range(j)] + [self.Up(node[r + 1, j - 1])]
+                node[r, j] = getattr(self, f"conv{r}_{j}")(torch.cat(parts, 1))
+        return self.final(node[0, 4])
+
+
+# ---------------------------------------------------------------------------------------------
+# Deterministic, torch-RNG-independent initialiser shared by the oracle, the tests and the fixtures
+# ---------------------------------------------------------------------------------------------
+def _splitmix64(x):
+    import numpy as np
+    x = (x + np.uint64(0x9E3779B97F4A7C15))
+    z = x
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def hash_uniform(tag, shape, lo=-1.0, hi=1.0):
+    """Uniform [lo,hi) values that depend only on `tag` and the flat element index."""
+    import zlib
+    import numpy as np
+    n = 1
+    for s in shape:
+        n *= int(s)
+    seed = np.uint64(zlib.crc32(tag.encode()) * 2654435761 % (1 << 63))
+    with np.errstate(over='ignore'):
+        bits = _splitmix64(np.arange(n, dtype=np.uint64) * np.uint64(0x2545F4914F6CDD1D) + seed)
+    u = (bits >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    return torch.from_numpy((lo + (hi - lo) * u).astype(np.float32).reshape(shape))
+
+
+def hash_init_(module, salt="w"):
+    """Fill a module's parameters and BN buffers by key name: conv weights ~ U(+-sqrt(3/fan_in))
+    (unit-variance preserving), biases small, BN gamma in [0.75,1.25], beta small."""
+    sd = module.state_dict()
+    for key, t in sd.items():
+        tag = f"{salt}:{key}"
+        if key.endswith("num_batches_tracked"):
+            t.zero_()
+        elif key.endswith("running_mean"):
+            t.copy_(hash_uniform(tag, t.shape, -0.1, 0.1))
+        elif key.endswith("running_var"):
+            t.copy_(hash_uniform(tag, t.shape, 0.8, 1.2))
+        elif t.dim() == 4:
+            fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+            bound = (6.0 / fan_in) ** 0.5      # He-uniform keeps activations O(1) through ReLU stacks
+            t.copy_(hash_uniform(tag, t.shape, -bound, bound))
+        elif key.endswith("weight"):           # BN gamma
+            t.copy_(hash_uniform(tag, t.shape, 0.75, 1.25))
+        else:                                  # biases / BN beta
+            t.copy_(hash_uniform(tag, t.shape, -0.1, 0.1))
+    module.load_state_dict(sd)
+    return module
+
+
+def synthetic_batch(n, side, n_classes, in_ch=3, tag="batch"):
+    """Grey z-scored slice replicated to `in_ch` channels (read_roi.py:183-187 convention) and a label
+    map with small filled ellipses; every 4th image is all background (exercises the fg filter)."""
+    import numpy as np
+    grey = hash_uniform(tag + ":img", (n, 1, side, side), -1.7320508, 1.7320508)
+    img = grey.expand(n, in_ch, side, side).contiguous()
+    yy, xx = np.mgrid[0:side, 0:side].astype(np.float32)
+    lab = np.zeros((n, side, side), dtype=np.int64)
+    for b in range(n):
+        if b % 4 == 3:
+            continue
+        for c in range(1, n_classes):
+            cy = side * (0.35 + 0.1 * c + 0.03 * b)
+            cx = side * (0.30 + 0.15 * c - 0.02 * b)
+            ry, rx = side * (0.06 + 0.01 * c), side * (0.09 + 0.01 * b)
+            lab[b][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = c
+    return img, torch.from_numpy(lab)
