@@ -1,0 +1,638 @@
+// Implicit-GEMM 3x3 / 1x1 convolutions on the gfx950 matrix cores (NHWC activations).
+//
+//   forward / data-gradient :  y[p][co] = sum_{tap,ci} x[p + off(tap)][ci] * w[co][tap][ci]
+//   weight-gradient         :  dw[co][tap][ci] = sum_p dy[p][co] * x[p + off(tap)][ci]
+//
+// Geometry shared by both kernels: a workgroup (4 wavefronts) owns a spatial tile of TH x 16 pixels
+// of one image.  Per 128-byte "K-row" of input channels (64 bf16 / 32 fp32) the tile's input halo
+// ((TH+2) x 18 pixels) is staged ONCE in LDS and re-used by all nine taps through shifted reads,
+// so the activation traffic into LDS is ~1.4x the tile instead of 9x.  LDS rows are 128 B; the
+// 16-byte slots of a row are XOR-swizzled with the row index so that the 16 pixels (or 16 output
+// channels) a ds_read_b128 group touches fall on distinct banks.  Packed weights are stored in
+// global memory already in that swizzled image, so staging them is a straight 16-B copy.
+//
+// MFMA orientation (forward): A = weights (rows = output channels), B = pixels (columns), so a lane's
+// four accumulator registers are four CONSECUTIVE output channels of one pixel -> one 8/16-byte store.
+#include "common.h"
+
+namespace segk {
+
+constexpr int kConvThreads = 256;
+constexpr int kRowBytes = 128;   // one K-row: 64 bf16 or 32 fp32 channels of one pixel / output channel
+constexpr int kTW = 16;          // tile width in pixels = MFMA N
+
+template <typename T> struct KRow { static constexpr int kElems = kRowBytes / (int)sizeof(T); };
+
+typedef uint4 Slot;   // 16 bytes
+
+struct ConvArgs {
+    const char* x0; const char* x1;   // input segments (bytes)
+    int64_t ld0, ld1;                 // pixel strides in elements
+    int C0, C1;                       // channels of each segment (a last partial K-row is zero-filled)
+    int nch0, nch;                    // K-rows in segment 0 / in total
+    int N, H, W, tiles_x, tiles_y;
+    const char* w;                    // packed weights [nch][TAPS][cout_pad][128 B]
+    int Cout, cout_pad;
+    const float* bias;
+    char* y; int64_t ldy;
+    const char* mask; int64_t ld_mask;
+    int relu, accumulate;
+};
+
+__device__ __forceinline__ Slot zero_slot() { return make_uint4(0u, 0u, 0u, 0u); }
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    // two k-substeps of 32 channels per K-row; slot = ks*4 + (lane>>4)
+    static __device__ __forceinline__ void run(const Slot& a, const Slot& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // a 16-byte slot holds 4 consecutive channels; lane group g of k-substep t reads slot t*4+g and
+    // issues 4 MFMAs, one per element: both operands use the same (slot, element) -> channel map.
+    static __device__ __forceinline__ void run(const Slot& a, const Slot& b, f32x4& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.x), __builtin_bit_cast(float, b.x), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.y), __builtin_bit_cast(float, b.y), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.z), __builtin_bit_cast(float, b.z), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES>
+__global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a) {
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_;
+    constexpr int HSLOTS = HPIX * 8;
+    constexpr int HL = (HSLOTS + TAPS * kConvThreads - 1) / (TAPS * kConvThreads);   // halo loads / thread / step
+    constexpr int WL = BN * 8 / kConvThreads;                                        // weight loads / thread / step
+    static_assert(BN * 8 % kConvThreads == 0, "weight tile must split evenly");
+    constexpr int WCO = BN / WCO_WAVES, WPX = TH * kTW / WPX_WAVES;
+    constexpr int NI = WCO / 16, NJ = WPX / 16;
+    static_assert(WPX_WAVES * WCO_WAVES == 4 && NI >= 1 && NJ >= 1, "bad wave layout");
+    constexpr int EPS = 16 / (int)sizeof(T);   // elements per 16-byte slot
+
+    __shared__ __attribute__((aligned(16))) char s_halo[2][HPIX * kRowBytes];
+    __shared__ __attribute__((aligned(16))) char s_w[2][BN * kRowBytes];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wpx = wave % WPX_WAVES, wco = wave / WPX_WAVES;
+
+    // block -> (output-channel block, image, tile): channel block slowest so that concurrently
+    // resident workgroups stream the same weight slab through L2.
+    const int nsp = a.N * a.tiles_y * a.tiles_x;
+    const int cb = blockIdx.x / nsp;
+    int sp = blockIdx.x % nsp;
+    const int tx = sp % a.tiles_x; sp /= a.tiles_x;
+    const int ty = sp % a.tiles_y;
+    const int n = sp / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * kTW;
+
+    // ---- staging helpers ---------------------------------------------------------------------
+    auto halo_src = [&](int chunk, int slot_id, bool& ok) -> const char* {
+        const int pix = slot_id >> 3, sl = slot_id & 7;
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
+        const bool s0 = chunk < a.nch0;
+        const char* base = s0 ? a.x0 : a.x1;
+        const int64_t ld = s0 ? a.ld0 : a.ld1;
+        const int ch = (s0 ? chunk : chunk - a.nch0) * KRow<T>::kElems + sl * EPS;
+        ok = slot_id < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < (s0 ? a.C0 : a.C1);
+        return base + ((((int64_t)n * a.H + gy) * a.W + gx) * ld + ch) * (int64_t)sizeof(T);
+    };
+    auto halo_dst = [&](int buf, int slot_id) -> char* {
+        const int pix = slot_id >> 3, sl = slot_id & 7;
+        return &s_halo[buf][pix * kRowBytes + ((sl ^ (pix & 7)) << 4)];
+    };
+    auto w_src = [&](int step, int q) -> const char* {
+        return a.w + (((int64_t)step * a.cout_pad + (int64_t)cb * BN) * kRowBytes) + (int64_t)q * 16;
+    };
+
+    Slot hreg[HL], wreg[WL];
+    const int nsteps = a.nch * TAPS;
+
+    // ---- prologue: whole halo of chunk 0 and the weights of step 0 ---------------------------------
+    for (int s = tid; s < HSLOTS; s += kConvThreads) {
+        bool ok;
+        const char* src = halo_src(0, s, ok);
+        *reinterpret_cast<Slot*>(halo_dst(0, s)) = ok ? *reinterpret_cast<const Slot*>(src) : zero_slot();
+    }
+#pragma unroll
+    for (int k = 0; k < WL; ++k) {
+        const int q = tid + k * kConvThreads;
+        *reinterpret_cast<Slot*>(&s_w[0][q * 16]) = *reinterpret_cast<const Slot*>(w_src(0, q));
+    }
+    __syncthreads();
+
+    f32x4 acc[NI][NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int chunk = 0, tap = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        const bool more = step + 1 < nsteps;
+        const bool next_halo = chunk + 1 < a.nch;
+        // issue the global loads of the next step early; they are consumed after the MFMAs
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < WL; ++k) wreg[k] = *reinterpret_cast<const Slot*>(w_src(step + 1, tid + k * kConvThreads));
+        }
+        if (next_halo) {
+#pragma unroll
+            for (int k = 0; k < HL; ++k) {
+                const int s = (tap * HL + k) * kConvThreads + tid;
+                bool ok;
+                const char* src = halo_src(chunk + 1, s, ok);
+                hreg[k] = ok ? *reinterpret_cast<const Slot*>(src) : zero_slot();
+            }
+        }
+        // ---- MFMAs of this (chunk, tap) on the current buffers -------------------------------------
+        const char* hb = s_halo[chunk & 1];
+        const char* wb = s_w[step & 1];
+        const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int slot = ks * 4 + g;
+            Slot fa[NI], fb[NJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int co = wco * WCO + i * 16 + l15;
+                fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int hp = (wpx * NJ + j + ky) * HW_ + l15 + kx;
+                fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        // ---- retire the prefetched data into the other buffers ------------------------------------
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < WL; ++k) *reinterpret_cast<Slot*>(&s_w[(step + 1) & 1][(tid + k * kConvThreads) * 16]) = wreg[k];
+        }
+        if (next_halo) {
+#pragma unroll
+            for (int k = 0; k < HL; ++k) {
+                const int s = (tap * HL + k) * kConvThreads + tid;
+                if (s < HSLOTS) *reinterpret_cast<Slot*>(halo_dst((chunk + 1) & 1, s)) = hreg[k];
+            }
+        }
+        __syncthreads();
+        if (++tap == TAPS) { tap = 0; ++chunk; }
+    }
+
+    // ---- epilogue: bias, ReLU, mask, store 4 consecutive channels per lane --------------------------
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
+        if (yy >= a.H || xx >= a.W) continue;
+        const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int co = cb * BN + wco * WCO + i * 16 + 4 * g;
+            if (co >= a.Cout) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.bias) {
+                const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (a.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+            }
+            if (a.mask) {
+                float m[4];
+                Elem<T>::load4(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
+            }
+            T* dst = reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
+            if (a.accumulate) {
+                float o[4];
+                Elem<T>::load4(dst, o);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += o[r];
+            }
+            Elem<T>::store4(dst, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: fp32 OIHW -> swizzled K-row images
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
+                                                                 int seg0, char* __restrict__ wf, char* __restrict__ wb) {
+    constexpr int EPS = 16 / (int)sizeof(T);
+    constexpr int KR = KRow<T>::kElems;
+    // forward image: rows = Cout rounded up to 32 per (chunk,tap); K = input channels, each input
+    // segment starting on a K-row boundary
+    const int cout_pad = (Cout + 31) / 32 * 32;
+    const int k0_pad = (seg0 + KR - 1) / KR * KR;                    // K-rows span of segment 0
+    const int kf_pad = k0_pad + (Cin - seg0 + KR - 1) / KR * KR;
+    const int64_t nf = wf ? (int64_t)(kf_pad / KR) * taps * cout_pad * 8 : 0;
+    // backward image: rows = dx channels (logical input channels, rounded up to 32); K = output channels
+    const int kb_pad = (Cout + KR - 1) / KR * KR;
+    const int rows_b = (Cin + 31) / 32 * 32;
+    const int64_t nb = wb ? (int64_t)(kb_pad / KR) * taps * rows_b * 8 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * kConvThreads + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * kConvThreads) {
+        const bool fwd = i < nf;
+        int64_t r = fwd ? i : i - nf;
+        const int sl = (int)(r & 7); r >>= 3;
+        const int rows = fwd ? cout_pad : rows_b;
+        const int row = (int)(r % rows); r /= rows;
+        const int tap = (int)(r % taps);
+        const int chunk = (int)(r / taps);
+        float v[EPS];
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) {
+            const int k = chunk * KR + sl * EPS + j;
+            int co, ci, t;
+            if (fwd) {
+                co = row; t = tap;
+                // K index -> logical input channel (-1 inside the zero padding that ends a segment)
+                if (k < k0_pad) ci = k < seg0 ? k : -1;
+                else ci = seg0 + (k - k0_pad);
+            } else { co = k; ci = row; t = taps - 1 - tap; }
+            v[j] = (co < Cout && ci >= 0 && ci < Cin) ? w[((int64_t)co * Cin + ci) * taps + t] : 0.f;
+        }
+        char* dst = (fwd ? wf : wb) + (((int64_t)chunk * taps + tap) * rows + row) * kRowBytes + ((sl ^ (row & 7)) << 4);
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+            *reinterpret_cast<bf16x8*>(dst) = o;
+        } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel.  Workgroup = (output-channel block of one K-row width, input K-row, pixel
+// split).  Both MFMA operands are needed "pixel-major" (K = pixels) while memory is channel-major;
+// for bf16 the transposing LDS read ds_read_b64_tr_b16 delivers exactly the A/B fragment layout from
+// the [pixel][channel] image, for fp32 a lane reads single elements.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const char* x0; const char* x1;
+    int64_t ld0, ld1;
+    int C0, C1;
+    int nch0, nch;
+    int N, H, W, tiles_x, tiles_y;
+    const char* dy; int64_t ldy;
+    int Cout, ncb;            // dy channels, output-channel blocks (of KRow elems)
+    int splits, tiles_per_split;
+    float* slab;              // [splits][ncb*KR][TAPS][nch*KR]
+};
+
+template <typename T> __device__ __forceinline__ int wg_swz(int pix);
+template <> __device__ __forceinline__ int wg_swz<bf16>(int pix) { return (((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2); }
+template <> __device__ __forceinline__ int wg_swz<float>(int pix) { return (pix & 1) << 2; }
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int TH = 8;
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_, TPIX = TH * kTW;
+    constexpr int KR = KRow<T>::kElems;
+    constexpr int EPS = 16 / (int)sizeof(T);
+    constexpr int TD = KR / 16;        // 16-wide tiles per block side: 4 (bf16) / 2 (fp32)
+    constexpr int WT = TD / 2;         // tiles per wave side (2x2 wave grid)
+    constexpr bool kBf16 = sizeof(T) == 2;
+
+    __shared__ __attribute__((aligned(16))) char s_x[HPIX * kRowBytes];
+    __shared__ __attribute__((aligned(16))) char s_dy[TPIX * kRowBytes];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, l15 = lane & 15;
+    const int wi = wave >> 1, wj = wave & 1;
+
+    int b = blockIdx.x;
+    const int split = b % a.splits; b /= a.splits;
+    const int chunk = b % a.nch;
+    const int cb = b / a.nch;
+
+    const bool s0 = chunk < a.nch0;
+    const char* xbase = s0 ? a.x0 : a.x1;
+    const int64_t ldx = s0 ? a.ld0 : a.ld1;
+    const int xch = (s0 ? chunk : chunk - a.nch0) * KR;
+    const int xcmax = s0 ? a.C0 : a.C1;
+
+    f32x4 acc[TAPS][WT][WT];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int ntiles = a.N * a.tiles_y * a.tiles_x;
+    const int t_lo = split * a.tiles_per_split;
+    const int t_hi = min(t_lo + a.tiles_per_split, ntiles);
+
+    for (int tile = t_lo; tile < t_hi; ++tile) {
+        int sp = tile;
+        const int tx = sp % a.tiles_x; sp /= a.tiles_x;
+        const int ty = sp % a.tiles_y;
+        const int n = sp / a.tiles_y;
+        const int y0 = ty * TH, x0 = tx * kTW;
+        __syncthreads();   // previous tile's reads are done
+        for (int s = tid; s < HPIX * 8; s += kConvThreads) {
+            const int pix = s >> 3, sl = s & 7;
+            const int hy = pix / HW_, hx = pix - hy * HW_;
+            const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
+            Slot v = zero_slot();
+            if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && xch + sl * EPS < xcmax)
+                v = *reinterpret_cast<const Slot*>(xbase + ((((int64_t)n * a.H + gy) * a.W + gx) * ldx + xch + sl * EPS) * (int64_t)sizeof(T));
+            *reinterpret_cast<Slot*>(&s_x[pix * kRowBytes + ((sl ^ wg_swz<T>(pix)) << 4)]) = v;
+        }
+        for (int s = tid; s < TPIX * 8; s += kConvThreads) {
+            const int pix = s >> 3, sl = s & 7;
+            const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+            const int ch = cb * KR + sl * EPS;
+            Slot v = zero_slot();
+            if (gy < a.H && gx < a.W && ch < a.Cout)
+                v = *reinterpret_cast<const Slot*>(a.dy + ((((int64_t)n * a.H + gy) * a.W + gx) * a.ldy + ch) * (int64_t)sizeof(T));
+            *reinterpret_cast<Slot*>(&s_dy[pix * kRowBytes + ((sl ^ wg_swz<T>(pix)) << 4)]) = v;
+        }
+        __syncthreads();
+
+        if constexpr (kBf16) {
+            // K-step = 32 pixels = two tile rows.  Lane (li = lane&15, g): q = li>>2, p = li&3 supplies the
+            // address of pixel row 8g+q (+4), 8-byte unit (tile*4 + p); it receives channel tile*16+li.
+            const int q = l15 >> 2, p = l15 & 3;
+            typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+#pragma unroll 1
+            for (int kk = 0; kk < TPIX / 32; ++kk) {
+                s16x8 fa[WT];
+                int kpix[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) kpix[h] = kk * 32 + 8 * g + q + 4 * h;
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    const int u = (wi * WT + i) * 4 + p;
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int pix = kpix[h];
+                        const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s16x4)(&s_dy[pix * kRowBytes + (((u >> 1) ^ wg_swz<T>(pix)) << 4) + (u & 1) * 8]));
+                        fa[i][4 * h + 0] = r[0]; fa[i][4 * h + 1] = r[1]; fa[i][4 * h + 2] = r[2]; fa[i][4 * h + 3] = r[3];
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) {
+                        const int u = (wj * WT + j) * 4 + p;
+                        s16x8 fb;
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int hp = ((kpix[h] >> 4) + ky) * HW_ + (kpix[h] & 15) + kx;
+                            const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                                (lds_s16x4)(&s_x[hp * kRowBytes + (((u >> 1) ^ wg_swz<T>(hp)) << 4) + (u & 1) * 8]));
+                            fb[4 * h + 0] = r[0]; fb[4 * h + 1] = r[1]; fb[4 * h + 2] = r[2]; fb[4 * h + 3] = r[3];
+                        }
+#pragma unroll
+                        for (int i = 0; i < WT; ++i)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
+                                                                                  __builtin_bit_cast(bf16x8, fb), acc[t][i][j], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // fp32: K-step = 4 pixels; lane (m = lane&15, k = lane>>4) reads one element of each operand.
+#pragma unroll 1
+            for (int kk = 0; kk < TPIX / 4; ++kk) {
+                const int pix = kk * 4 + g;
+                float fa[WT];
+#pragma unroll
+                for (int i = 0; i < WT; ++i) {
+                    const int c = (wi * WT + i) * 16 + l15;
+                    fa[i] = *reinterpret_cast<const float*>(&s_dy[pix * kRowBytes + ((((c >> 2) ^ wg_swz<T>(pix)) << 4) | ((c & 3) << 2))]);
+                }
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                    const int hp = ((pix >> 4) + ky) * HW_ + (pix & 15) + kx;
+#pragma unroll
+                    for (int j = 0; j < WT; ++j) {
+                        const int c = (wj * WT + j) * 16 + l15;
+                        const float fb = *reinterpret_cast<const float*>(&s_x[hp * kRowBytes + ((((c >> 2) ^ wg_swz<T>(hp)) << 4) | ((c & 3) << 2))]);
+#pragma unroll
+                        for (int i = 0; i < WT; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb, acc[t][i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // partial slab: slab[split][co][tap][ci]
+    const int cin_tot = a.nch * KR;
+    const int64_t co_tot = (int64_t)a.ncb * KR;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int i = 0; i < WT; ++i)
+#pragma unroll
+            for (int j = 0; j < WT; ++j) {
+                const int ci = chunk * KR + (wj * WT + j) * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int co = cb * KR + (wi * WT + i) * 16 + 4 * g + r;
+                    a.slab[(((int64_t)split * co_tot + co) * TAPS + t) * cin_tot + ci] = acc[t][i][j][r];
+                }
+            }
+}
+
+// dw[co][ci][tap] (OIHW) (+)= sum_splits slab[s][co][tap][ci]
+__global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t co_tot,
+                                                                         int taps, int cin_tot, int cout_real, int cin_real,
+                                                                         int seg0, int k0_pad, float* __restrict__ dw,
+                                                                         int accumulate) {
+    const int64_t total = (int64_t)cout_real * cin_real * taps;
+    for (int64_t i = (int64_t)blockIdx.x * kConvThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kConvThreads) {
+        // iterate with ci fastest so that slab reads are coalesced
+        const int ci = (int)(i % cin_real);
+        int64_t r = i / cin_real;
+        const int t = (int)(r % taps);
+        const int co = (int)(r / taps);
+        const int kc = ci < seg0 ? ci : k0_pad + (ci - seg0);   // position in the K-row-padded channel space
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(((int64_t)k * co_tot + co) * taps + t) * cin_tot + kc];
+        float* d = dw + ((int64_t)co * cin_real + ci) * taps + t;
+        *d = accumulate ? *d + s : s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+static inline int krow(int dtype) { return dtype == SEGK_BF16 ? 64 : 32; }
+static inline int pick_bn(int64_t cout_pad) { return cout_pad % 128 == 0 ? 128 : (cout_pad % 64 == 0 ? 64 : 32); }
+
+template <typename T, int TAPS>
+static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
+    const unsigned grid = (unsigned)((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn));
+    if (bn == 128)
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 128, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
+    else if (bn == 64)
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 64, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 32, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);
+}
+
+static int wgrad_splits(int64_t ntiles, int64_t ncb, int64_t nch) {
+    int64_t s = (1536 + ncb * nch - 1) / (ncb * nch);
+    if (s > ntiles) s = ntiles;
+    if (s > 256) s = 256;
+    if (s < 1) s = 1;
+    // even out the tile ranges
+    const int64_t per = (ntiles + s - 1) / s;
+    return (int)((ntiles + per - 1) / per);
+}
+
+static int check_segments(const char* who, int dtype, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
+                          int64_t C1) {
+    const int kr = krow(dtype);
+    if (dtype != SEGK_F32 && dtype != SEGK_BF16) return fail(SEGK_EINVAL, "%s: unknown dtype %d", who, dtype);
+    (void)kr;
+    if (!x0 || C0 <= 0 || C0 % 8) return fail(SEGK_ESHAPE, "%s: segment 0 channels %lld must be a positive multiple of 8", who, (long long)C0);
+    if (ld0 < C0 || !aligned16(x0) || (ld0 * esize(dtype)) % 16) return fail(SEGK_EALIGN, "%s: segment 0 pointer/ld misaligned or ld < C", who);
+    if (C1 != 0) {
+        if (!x1 || C1 < 0 || C1 % 8) return fail(SEGK_ESHAPE, "%s: segment 1 channels %lld must be a multiple of 8", who, (long long)C1);
+        if (ld1 < C1 || !aligned16(x1) || (ld1 * esize(dtype)) % 16) return fail(SEGK_EALIGN, "%s: segment 1 pointer/ld misaligned or ld < C", who);
+    }
+    return SEGK_OK;
+}
+
+}  // namespace segk
+
+using namespace segk;
+
+extern "C" int segk_conv_krow(int dtype) { return krow(dtype); }
+
+extern "C" size_t segk_conv_packed_bytes(int dtype, int64_t Cout, int64_t Cin, int taps, int64_t seg0) {
+    if (Cout <= 0 || Cin <= 0 || (taps != 1 && taps != 9) || seg0 < 0 || seg0 > Cin) return 0;
+    const int kr = krow(dtype);
+    if (seg0 == 0) seg0 = Cin;
+    const int64_t kf = round_up(seg0, kr) + round_up(Cin - seg0, kr);
+    const int64_t f = kf / kr * taps * round_up(Cout, 32) * kRowBytes;
+    const int64_t b = round_up(Cout, kr) / kr * taps * round_up(Cin, 32) * kRowBytes;
+    return (size_t)(f > b ? f : b);
+}
+
+extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, int taps, int64_t seg0, int dtype, void* wf,
+                              void* wb, int dev, void* stream) {
+    SEGK_REQUIRE(w_oihw && (wf || wb), SEGK_EINVAL, "conv_pack: null pointer");
+    SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_pack: taps must be 1 or 9");
+    SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "conv_pack: unknown dtype");
+    SEGK_REQUIRE(Cout > 0 && Cin > 0 && seg0 >= 0 && seg0 <= Cin, SEGK_ESHAPE, "conv_pack: bad channel counts (Cout=%lld Cin=%lld seg0=%lld)",
+                 (long long)Cout, (long long)Cin, (long long)seg0);
+    SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "conv_pack: packed buffers must be 16-byte aligned");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    if (seg0 == 0) seg0 = Cin;
+    const int64_t kf = round_up(seg0, kr) + round_up(Cin - seg0, kr);
+    const int64_t slots = ((wf ? kf / kr * round_up(Cout, 32) : 0) + (wb ? round_up(Cout, kr) / kr * round_up(Cin, 32) : 0)) * taps * 8;
+    int64_t grid = (slots + kConvThreads - 1) / kConvThreads;
+    if (grid > 4096) grid = 4096;
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3((unsigned)grid), dim3(kConvThreads), 0, (hipStream_t)stream,
+                                                     w_oihw, (int)Cout, (int)Cin, taps, (int)seg0, (char*)wf, (char*)wb));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1, int64_t C1,
+                             int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout, const float* bias, void* y,
+                             int64_t ldy, const void* mask, int64_t ld_mask, int flags, int dev, void* stream) {
+    if (int rc = check_segments("conv_fwd", dtype, x0, ld0, C0, x1, ld1, C1)) return rc;
+    SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_fwd: taps must be 1 or 9");
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_fwd: bad N/H/W");
+    SEGK_REQUIRE(w_packed && y && aligned16(w_packed), SEGK_EINVAL, "conv_fwd: null or misaligned weights/output");
+    SEGK_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldy >= Cout, SEGK_ESHAPE, "conv_fwd: Cout %lld must be a multiple of 4 and <= ldy", (long long)Cout);
+    SEGK_REQUIRE(aligned16(y) && (ldy * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_fwd: output pointer/ld misaligned");
+    SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "conv_fwd: bias must be 16-byte aligned");
+    SEGK_REQUIRE(!mask || (aligned16(mask) && ld_mask >= Cout && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "conv_fwd: mask misaligned");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    ConvArgs a;
+    a.x0 = (const char*)x0; a.x1 = (const char*)x1; a.ld0 = ld0; a.ld1 = ld1;
+    a.C0 = (int)C0; a.C1 = (int)C1;
+    a.nch0 = (int)(round_up(C0, kr) / kr); a.nch = a.nch0 + (int)(round_up(C1, kr) / kr);
+    a.N = (int)N; a.H = (int)H; a.W = (int)W;
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.w = (const char*)w_packed; a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
+    a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = (const char*)mask; a.ld_mask = ld_mask;
+    a.relu = flags & 1; a.accumulate = (flags >> 1) & 1;
+    const int bn = pick_bn(a.cout_pad);
+    SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv_fwd: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (taps == 9) SEGK_DISPATCH_DTYPE(dtype, T, (launch_fwd_t<T, 9>(a, bn, st)));
+    else SEGK_DISPATCH_DTYPE(dtype, T, (launch_fwd_t<T, 1>(a, bn, st)));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" size_t segk_conv_wgrad_workspace(int dtype, int taps, int64_t C0, int64_t C1, int64_t N, int64_t H, int64_t W,
+                                            int64_t Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0 || C0 <= 0 || C1 < 0) return 0;
+    const int kr = krow(dtype);
+    const int64_t nch = round_up(C0, kr) / kr + round_up(C1, kr) / kr, ncb = (Cout + kr - 1) / kr;
+    const int64_t ntiles = N * ((H + 7) / 8) * ((W + kTW - 1) / kTW);
+    const int s = wgrad_splits(ntiles, ncb, nch);
+    return align_up((size_t)s * ncb * kr * taps * nch * kr * sizeof(float), 256);
+}
+
+extern "C" int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
+                               int64_t C1, int64_t N, int64_t H, int64_t W, const void* dy, int64_t ldy, int64_t Cout,
+                               int64_t cin_real, float* dw, int flags, void* workspace, size_t workspace_bytes, int dev,
+                               void* stream) {
+    if (int rc = check_segments("conv_wgrad", dtype, x0, ld0, C0, x1, ld1, C1)) return rc;
+    SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_wgrad: taps must be 1 or 9");
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_wgrad: bad N/H/W");
+    SEGK_REQUIRE(dy && dw && workspace, SEGK_EINVAL, "conv_wgrad: null pointer");
+    SEGK_REQUIRE(Cout > 0 && Cout % 8 == 0 && ldy >= Cout && cin_real > 0 && cin_real <= C0 + C1 && (C1 == 0 || cin_real == C0 + C1),
+                 SEGK_ESHAPE, "conv_wgrad: bad channel counts (Cout=%lld cin_real=%lld)", (long long)Cout, (long long)cin_real);
+    SEGK_REQUIRE(aligned16(dy) && (ldy * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_wgrad: dy pointer/ld misaligned");
+    SEGK_REQUIRE(workspace_bytes >= segk_conv_wgrad_workspace(dtype, taps, C0, C1, N, H, W, Cout), SEGK_EWORKSPACE, "conv_wgrad: workspace too small");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    WgradArgs a;
+    a.x0 = (const char*)x0; a.x1 = (const char*)x1; a.ld0 = ld0; a.ld1 = ld1;
+    a.C0 = (int)C0; a.C1 = (int)C1;
+    a.nch0 = (int)(round_up(C0, kr) / kr); a.nch = a.nch0 + (int)(round_up(C1, kr) / kr);
+    a.N = (int)N; a.H = (int)H; a.W = (int)W;
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.dy = (const char*)dy; a.ldy = ldy; a.Cout = (int)Cout; a.ncb = (int)((Cout + kr - 1) / kr);
+    const int64_t ntiles = (int64_t)a.N * a.tiles_x * a.tiles_y;
+    a.splits = wgrad_splits(ntiles, a.ncb, a.nch);
+    a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
+    a.slab = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
+    if (taps == 9) SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_wgrad_kernel<T, 9>), dim3(grid), dim3(kConvThreads), 0, st, a));
+    else SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_wgrad_kernel<T, 1>), dim3(grid), dim3(kConvThreads), 0, st, a));
+    SEGK_LAUNCH_CHECK();
+    const int64_t total = Cout * cin_real * taps;
+    int64_t rgrid = (total + kConvThreads - 1) / kConvThreads;
+    if (rgrid > 8192) rgrid = 8192;
+    const int seg0 = C1 ? (int)C0 : (int)cin_real;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(kConvThreads), 0, st, (const float*)workspace, a.splits,
+                       (int64_t)a.ncb * kr, taps, a.nch * kr, (int)Cout, (int)cin_real, seg0, a.nch0 * kr, dw, (flags >> 1) & 1);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}

@@ -1,0 +1,945 @@
+// HBM-bound streaming kernels on NHWC activations: layout conversion, BatchNorm/InstanceNorm
+// statistics / apply / backward, ReLU masks, 2x2 max pool, bilinear x2 up-sampling (fused with
+// InstanceNorm-apply + ReLU), column sums, the 1x1 classification head and the Adam update.
+// Every thread moves 8 consecutive channels (16 B of bf16 / 32 B of fp32) of one pixel, so a
+// wavefront touches whole 128-B lines; reductions are two-stage with a fixed-order finalize.
+#include "common.h"
+
+namespace segk {
+
+constexpr int kThreads = 256;
+
+static inline int grid_for(int64_t items, int cap = 8192) {
+    int64_t g = (items + kThreads - 1) / kThreads;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------ layout conversion
+template <typename T>
+__global__ __launch_bounds__(kThreads) void nchw_to_nhwc_kernel(const float* __restrict__ src, int64_t N, int Cin,
+                                                                int64_t HW, T* __restrict__ dst, int Cout, int64_t ld) {
+    const int cv = Cout / 8;
+    const int64_t items = N * HW * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        const int64_t p = i / cv, n = p / HW, hw = p % HW;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = v * 8 + j;
+            o[j] = c < Cin ? src[(n * Cin + c) * HW + hw] : 0.f;
+        }
+        Elem<T>::store8(dst + p * ld + v * 8, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void im2col3x3_kernel(const float* __restrict__ src, int64_t N, int Cin, int H,
+                                                             int W, T* __restrict__ dst, int Cout, int64_t ld) {
+    const int cv = Cout / 8;
+    const int64_t HW = (int64_t)H * W, items = N * HW * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        const int64_t p = i / cv, n = p / HW;
+        const int hw = (int)(p % HW), y = hw / W, x = hw % W;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = v * 8 + j;
+            float val = 0.f;
+            if (k < 9 * Cin) {
+                const int tap = k / Cin, c = k % Cin;
+                const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) val = src[(n * Cin + c) * HW + (int64_t)yy * W + xx];
+            }
+            o[j] = val;
+        }
+        Elem<T>::store8(dst + p * ld + v * 8, o);
+    }
+}
+
+// ------------------------------------------------------------------------------ statistics
+// Block (b, g) sums its pixel range of group g for all channels.  partial layout:
+//   ws[((g*bpg + b)*2 + k)*C + c],  k = 0: sum, 1: sum of squares (or the two backward sums)
+struct RowSplit {
+    int cv, rows;  // channel vectors per pixel, pixel rows handled per block iteration
+};
+
+template <typename T, int MODE>  // MODE 0: sum x, sum x^2 ; MODE 1: column sum only
+__global__ __launch_bounds__(kThreads) void stats_partial_kernel(const T* __restrict__ x, int64_t ld, int64_t M, int C,
+                                                                 int bpg, float* __restrict__ ws) {
+    __shared__ float red[kThreads][17];
+    const int cv = C / 8, rows = kThreads / cv;
+    const int v = threadIdx.x % cv, r = threadIdx.x / cv;
+    const int g = blockIdx.y, b = blockIdx.x;
+    const int64_t per = (M + bpg - 1) / bpg;
+    const int64_t lo = (int64_t)b * per, hi = (lo + per < M) ? lo + per : M;
+    const T* base = x + (int64_t)g * M * ld + v * 8;
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (int64_t p = lo + r; p < hi; p += rows) {
+        float a[8];
+        Elem<T>::load8(base + p * ld, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s[j] += a[j]; if (MODE == 0) q[j] += a[j] * a[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s[j]; red[threadIdx.x][8 + j] = q[j]; }
+    __syncthreads();
+    // thread t < C*2 produces channel t%C of sum kind t/C, adding the rows in fixed order
+    for (int t = threadIdx.x; t < 2 * C; t += kThreads) {
+        const int k = t / C, c = t % C;
+        if (MODE == 1 && k == 1) continue;
+        float acc = 0.f;
+        for (int rr = 0; rr < rows; ++rr) acc += red[rr * cv + c / 8][k * 8 + (c & 7)];
+        ws[(((int64_t)g * bpg + b) * 2 + k) * C + c] = acc;
+    }
+}
+
+// mean / rstd per (group, channel) + optional running-buffer update (BatchNorm, groups == 1)
+__global__ __launch_bounds__(kThreads) void stats_finalize_kernel(const float* __restrict__ ws, int bpg, int64_t M, int C,
+                                                                  float eps, float* __restrict__ stats,
+                                                                  float* __restrict__ rmean, float* __restrict__ rvar,
+                                                                  float momentum) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < bpg; ++b) {
+        s += (double)ws[(((int64_t)g * bpg + b) * 2 + 0) * C + c];
+        q += (double)ws[(((int64_t)g * bpg + b) * 2 + 1) * C + c];
+    }
+    const double mean = s / (double)M;
+    double var = q / (double)M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[((int64_t)g * C + c) * 2 + 0] = (float)mean;
+    stats[((int64_t)g * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean && g == 0) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        rmean[c] = (float)((1.0 - momentum) * (double)rmean[c] + momentum * mean);
+        rvar[c] = (float)((1.0 - momentum) * (double)rvar[c] + momentum * unbiased);
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void eval_stats_kernel(const float* __restrict__ rmean, const float* __restrict__ rvar,
+                                                              int C, float eps, float* __restrict__ stats) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    stats[c * 2 + 0] = rmean[c];
+    stats[c * 2 + 1] = 1.f / sqrtf(rvar[c] + eps);
+}
+
+__global__ __launch_bounds__(kThreads) void colsum_finalize_kernel(const float* __restrict__ ws, int bpg, int C,
+                                                                   float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < bpg; ++b) s += (double)ws[((int64_t)b * 2 + 0) * C + c];
+    out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// ------------------------------------------------------------------------------ normalise (+ReLU)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restrict__ x, int64_t ldx, int64_t M, int C,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, int relu,
+                                                              T* __restrict__ y, int64_t ldy) {
+    const int cv = C / 8, rows = kThreads / cv;
+    const int v = threadIdx.x % cv, r = threadIdx.x / cv;
+    const int g = blockIdx.y;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        const float mean = stats[((int64_t)g * C + c) * 2], rstd = stats[((int64_t)g * C + c) * 2 + 1];
+        sc[j] = rstd * (gamma ? gamma[c] : 1.f);
+        sh[j] = (beta ? beta[c] : 0.f) - mean * sc[j];
+    }
+    const T* xb = x + (int64_t)g * M * ldx + v * 8;
+    T* yb = y + (int64_t)g * M * ldy + v * 8;
+    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M; p += (int64_t)gridDim.x * rows) {
+        float a[8];
+        Elem<T>::load8(xb + p * ldx, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a[j] = a[j] * sc[j] + sh[j];
+            if (relu) a[j] = fmaxf(a[j], 0.f);
+        }
+        Elem<T>::store8(yb + p * ldy, a);
+    }
+}
+
+// backward, pass 1: per block  s1 = sum g, s2 = sum g*xhat   (g = dy masked by the ReLU of the forward)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __restrict__ dy, int64_t ld_dy,
+                                                                    const T* __restrict__ x, int64_t ldx, int64_t M, int C,
+                                                                    const float* __restrict__ stats,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int relu, int bpg,
+                                                                    float* __restrict__ ws) {
+    __shared__ float red[kThreads][17];
+    const int cv = C / 8, rows = kThreads / cv;
+    const int v = threadIdx.x % cv, r = threadIdx.x / cv;
+    const int g = blockIdx.y, b = blockIdx.x;
+    float mean[8], rstd[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        mean[j] = stats[((int64_t)g * C + c) * 2];
+        rstd[j] = stats[((int64_t)g * C + c) * 2 + 1];
+        ga[j] = gamma ? gamma[c] : 1.f;
+        be[j] = beta ? beta[c] : 0.f;
+    }
+    const int64_t per = (M + bpg - 1) / bpg;
+    const int64_t lo = (int64_t)b * per, hi = (lo + per < M) ? lo + per : M;
+    const T* xb = x + (int64_t)g * M * ldx + v * 8;
+    const T* db = dy + (int64_t)g * M * ld_dy + v * 8;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    for (int64_t p = lo + r; p < hi; p += rows) {
+        float a[8], d[8];
+        Elem<T>::load8(xb + p * ldx, a);
+        Elem<T>::load8(db + p * ld_dy, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sc = rstd[j] * ga[j];
+            const float pre = a[j] * sc + (be[j] - mean[j] * sc);   // same expression as the forward
+            const float xh = (a[j] - mean[j]) * rstd[j];
+            const float gg = (relu && !(pre > 0.f)) ? 0.f : d[j];
+            s1[j] += gg;
+            s2[j] += gg * xh;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][8 + j] = s2[j]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += kThreads) {
+        const int k = t / C, c = t % C;
+        float acc = 0.f;
+        for (int rr = 0; rr < rows; ++rr) acc += red[rr * cv + c / 8][k * 8 + (c & 7)];
+        ws[(((int64_t)g * bpg + b) * 2 + k) * C + c] = acc;
+    }
+}
+
+// pass 1b: red[(g*C+c)*2 + {0,1}] = {s1, s2}; dgamma/dbeta; bias gradient of a frozen-statistics norm
+__global__ __launch_bounds__(kThreads) void norm_bwd_finalize_kernel(const float* __restrict__ ws, int bpg, int C,
+                                                                     float* __restrict__ red, float* __restrict__ dgamma,
+                                                                     float* __restrict__ dbeta, int accumulate) {
+    const int g = blockIdx.y;
+    const int c = blockIdx.x * kThreads + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < bpg; ++b) {
+        s1 += (double)ws[(((int64_t)g * bpg + b) * 2 + 0) * C + c];
+        s2 += (double)ws[(((int64_t)g * bpg + b) * 2 + 1) * C + c];
+    }
+    red[((int64_t)g * C + c) * 2 + 0] = (float)s1;
+    red[((int64_t)g * C + c) * 2 + 1] = (float)s2;
+    if (dgamma && g == 0) {
+        dgamma[c] = accumulate ? dgamma[c] + (float)s2 : (float)s2;
+        dbeta[c] = accumulate ? dbeta[c] + (float)s1 : (float)s1;
+    }
+}
+
+// pass 2: dx = gamma*rstd*(g - s1/M - xhat*s2/M)     (frozen: dx = gamma*rstd*g)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restrict__ dy, int64_t ld_dy,
+                                                               const T* __restrict__ x, int64_t ldx, int64_t M, int C,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int relu, int frozen,
+                                                               const float* __restrict__ red, T* __restrict__ dx,
+                                                               int64_t ld_dx) {
+    const int cv = C / 8, rows = kThreads / cv;
+    const int v = threadIdx.x % cv, r = threadIdx.x / cv;
+    const int g = blockIdx.y;
+    float mean[8], rstd[8], ga[8], be[8], m1[8], m2[8];
+    const float invM = 1.f / (float)M;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        mean[j] = stats[((int64_t)g * C + c) * 2];
+        rstd[j] = stats[((int64_t)g * C + c) * 2 + 1];
+        ga[j] = gamma ? gamma[c] : 1.f;
+        be[j] = beta ? beta[c] : 0.f;
+        m1[j] = frozen ? 0.f : red[((int64_t)g * C + c) * 2] * invM;
+        m2[j] = frozen ? 0.f : red[((int64_t)g * C + c) * 2 + 1] * invM;
+    }
+    const T* xb = x + (int64_t)g * M * ldx + v * 8;
+    const T* db = dy + (int64_t)g * M * ld_dy + v * 8;
+    T* ob = dx + (int64_t)g * M * ld_dx + v * 8;
+    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M; p += (int64_t)gridDim.x * rows) {
+        float a[8], d[8];
+        Elem<T>::load8(xb + p * ldx, a);
+        Elem<T>::load8(db + p * ld_dy, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sc = rstd[j] * ga[j];
+            const float pre = a[j] * sc + (be[j] - mean[j] * sc);
+            const float xh = (a[j] - mean[j]) * rstd[j];
+            const float gg = (relu && !(pre > 0.f)) ? 0.f : d[j];
+            d[j] = sc * (gg - m1[j] - xh * m2[j]);
+        }
+        Elem<T>::store8(ob + p * ld_dx, d);
+    }
+}
+
+// ------------------------------------------------------------------------------ 2x2 max pool
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restrict__ x, int64_t ldx, int64_t N, int H, int W,
+                                                               int C, T* __restrict__ y, int64_t ldy) {
+    const int cv = C / 8, Ho = H / 2, Wo = W / 2;
+    const int64_t items = N * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        int64_t p = i / cv;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int64_t n = p / Ho;
+        const T* s = x + ((n * H + 2 * oy) * W + 2 * ox) * ldx + v * 8;
+        float a[8], b[8], c[8], d[8];
+        Elem<T>::load8(s, a);
+        Elem<T>::load8(s + ldx, b);
+        Elem<T>::load8(s + (int64_t)W * ldx, c);
+        Elem<T>::load8(s + (int64_t)W * ldx + ldx, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = fmaxf(fmaxf(a[j], b[j]), fmaxf(c[j], d[j]));
+        Elem<T>::store8(y + ((n * Ho + oy) * Wo + ox) * ldy + v * 8, a);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ dy,
+                                                               int64_t ld_dy, int64_t N, int H, int W, int C,
+                                                               T* __restrict__ dx, int64_t ld_dx, int accumulate) {
+    const int cv = C / 8, Ho = H / 2, Wo = W / 2;
+    const int64_t items = N * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        int64_t p = i / cv;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int64_t n = p / Ho;
+        const int64_t o00 = ((n * H + 2 * oy) * W + 2 * ox);
+        const int64_t off[4] = {o00, o00 + 1, o00 + W, o00 + W + 1};
+        float in[4][8], g[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Elem<T>::load8(x + off[k] * ldx + v * 8, in[k]);
+        Elem<T>::load8(dy + ((n * Ho + oy) * Wo + ox) * ld_dy + v * 8, g);
+        int arg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float best = in[0][j];
+            arg[j] = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (in[k][j] > best) { best = in[k][j]; arg[j] = k; }   // first maximum in scan order wins
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o[8];
+            if (accumulate) Elem<T>::load8(dx + off[k] * ld_dx + v * 8, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float r = arg[j] == k ? g[j] : 0.f;
+                o[j] = accumulate ? o[j] + r : r;
+            }
+            Elem<T>::store8(dx + off[k] * ld_dx + v * 8, o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ bilinear x2
+struct Lerp { int i0, i1; float w0, w1; };
+
+// source taps of output index `o` (size 2*in) exactly as ATen's upsample_bilinear2d forms them
+__device__ __forceinline__ Lerp lerp_taps(int o, int in, bool align) {
+    float src;
+    if (align) {
+        const float scale = in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f;
+        src = scale * (float)o;
+    } else {
+        src = 0.5f * ((float)o + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    Lerp l;
+    l.i0 = (int)src;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_fwd_kernel(const T* __restrict__ x, int64_t ldx, int64_t N, int H, int W,
+                                                                int C, const float* __restrict__ stats, int relu, int align,
+                                                                T* __restrict__ y, int64_t ldy) {
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const int64_t items = N * Ho * Wo * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        int64_t p = i / cv;
+        const int ox = (int)(p % Wo); p /= Wo;
+        const int oy = (int)(p % Ho);
+        const int64_t n = p / Ho;
+        const Lerp ly = lerp_taps(oy, H, align != 0), lx = lerp_taps(ox, W, align != 0);
+        const T* b = x + n * H * W * ldx + v * 8;
+        float a00[8], a01[8], a10[8], a11[8], o[8];
+        Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i0) * ldx, a00);
+        Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i1) * ldx, a01);
+        Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i0) * ldx, a10);
+        Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i1) * ldx, a11);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float val = ly.w0 * (lx.w0 * a00[j] + lx.w1 * a01[j]) + ly.w1 * (lx.w0 * a10[j] + lx.w1 * a11[j]);
+            if (stats) {
+                const int c = v * 8 + j;
+                val = (val - stats[(n * C + c) * 2]) * stats[(n * C + c) * 2 + 1];
+            }
+            o[j] = relu ? fmaxf(val, 0.f) : val;
+        }
+        Elem<T>::store8(y + ((n * Ho + oy) * Wo + ox) * ldy + v * 8, o);
+    }
+}
+
+// adjoint of the interpolation (gather form): every input pixel collects from the output pixels whose
+// taps include it.  For x2 up-sampling those lie in [2h-3, 2h+3] for either corner convention.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy,
+                                                                const T* __restrict__ y, int64_t ldy, int64_t N, int H, int W,
+                                                                int C, int relu, int align, T* __restrict__ dx,
+                                                                int64_t ld_dx) {
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const int64_t items = N * H * W * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        int64_t p = i / cv;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int64_t n = p / H;
+        float wy[7], wx[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const int oy = 2 * h - 3 + k, ox = 2 * w - 3 + k;
+            wy[k] = 0.f; wx[k] = 0.f;
+            if (oy >= 0 && oy < Ho) {
+                const Lerp l = lerp_taps(oy, H, align != 0);
+                wy[k] = (l.i0 == h ? l.w0 : 0.f) + (l.i1 == h ? l.w1 : 0.f);
+            }
+            if (ox >= 0 && ox < Wo) {
+                const Lerp l = lerp_taps(ox, W, align != 0);
+                wx[k] = (l.i0 == w ? l.w0 : 0.f) + (l.i1 == w ? l.w1 : 0.f);
+            }
+        }
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int ky = 0; ky < 7; ++ky) {
+            if (wy[ky] == 0.f) continue;
+            const int oy = 2 * h - 3 + ky;
+            for (int kx = 0; kx < 7; ++kx) {
+                if (wx[kx] == 0.f) continue;
+                const int ox = 2 * w - 3 + kx;
+                const int64_t op = (n * Ho + oy) * Wo + ox;
+                float d[8];
+                Elem<T>::load8(dy + op * ld_dy + v * 8, d);
+                const float wgt = wy[ky] * wx[kx];
+                if (relu) {
+                    float f[8];
+                    Elem<T>::load8(y + op * ldy + v * 8, f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += (f[j] > 0.f) ? wgt * d[j] : 0.f;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += wgt * d[j];
+                }
+            }
+        }
+        Elem<T>::store8(dx + ((n * H + h) * W + w) * ld_dx + v * 8, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------ slices
+template <typename T>
+__global__ __launch_bounds__(kThreads) void copy_slice_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst,
+                                                              int64_t ld_dst, int64_t P, int C, int accumulate) {
+    const int cv = C / 8;
+    const int64_t items = P * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        const int64_t p = i / cv;
+        float a[8];
+        Elem<T>::load8(src + p * ld_src + v * 8, a);
+        if (accumulate) {
+            float b[8];
+            Elem<T>::load8(dst + p * ld_dst + v * 8, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += b[j];
+        }
+        Elem<T>::store8(dst + p * ld_dst + v * 8, a);
+    }
+}
+
+// ------------------------------------------------------------------------------ 1x1 head
+constexpr int kHeadMaxOut = 8;
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void head_fwd_kernel(const T* __restrict__ x, int64_t ld, int Cin, int64_t N,
+                                                            int64_t HW, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int Cout,
+                                                            float* __restrict__ logits) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [Cout][Cin] + [Cout]
+    for (int i = threadIdx.x; i < Cout * Cin; i += kThreads) wsm[i] = w[i];
+    for (int i = threadIdx.x; i < Cout; i += kThreads) wsm[Cout * Cin + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int64_t P = N * HW;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < P; p += (int64_t)gridDim.x * kThreads) {
+        float acc[kHeadMaxOut];
+#pragma unroll
+        for (int c = 0; c < kHeadMaxOut; ++c) acc[c] = c < Cout ? wsm[Cout * Cin + c] : 0.f;
+        for (int k = 0; k < Cin; k += 8) {
+            float a[8];
+            Elem<T>::load8(x + p * ld + k, a);
+#pragma unroll
+            for (int c = 0; c < kHeadMaxOut; ++c)
+                if (c < Cout) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[c] += a[j] * wsm[c * Cin + k + j];
+                }
+        }
+        const int64_t n = p / HW, hw = p % HW;
+#pragma unroll
+        for (int c = 0; c < kHeadMaxOut; ++c)
+            if (c < Cout) logits[(n * Cout + c) * HW + hw] = acc[c];
+    }
+}
+
+// backward: item = (pixel, 8-channel vector).  dx = sum_c dl[c]*w[c][ci] (masked by x>0 when the head's
+// input is a ReLU output); per-thread dw[c][8] accumulators reduced over lanes sharing the channel vector.
+// partial layout: ws[b*(Cout*Cin + Cout) + ...] = dw[c][ci] then db[c]
+template <typename T, int COUT>
+__global__ __launch_bounds__(kThreads) void head_bwd_kernel(const T* __restrict__ x, int64_t ld, int Cin, int64_t N,
+                                                            int64_t HW, const float* __restrict__ w,
+                                                            const float* __restrict__ dlogits, T* __restrict__ dx,
+                                                            int64_t ld_dx, int relu_mask, float* __restrict__ ws) {
+    __shared__ float red[kThreads / 64][8][COUT * 8 + 1];   // [wave][channel vector][c*8+j], padded against bank conflicts
+    __shared__ float dbs[kThreads / 64][COUT];
+    const int cv = Cin / 8;                      // 4 or 8 (Cin 32 / 64): divides 64
+    const int v = threadIdx.x % cv;
+    const int64_t P = N * HW, items = P * cv;
+    float wr[COUT][8], acc[COUT][8], db[COUT];
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+        db[c] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { wr[c][j] = w[c * Cin + v * 8 + j]; acc[c][j] = 0.f; }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = i / cv, n = p / HW, hw = p % HW;
+        float a[8], o[8], dl[COUT];
+        Elem<T>::load8(x + p * ld + v * 8, a);
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) dl[c] = dlogits[(n * COUT + c) * HW + hw];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) { s += dl[c] * wr[c][j]; acc[c][j] += dl[c] * a[j]; }
+            o[j] = (relu_mask && !(a[j] > 0.f)) ? 0.f : s;
+        }
+        if (v == 0) {
+#pragma unroll
+            for (int c = 0; c < COUT; ++c) db[c] += dl[c];
+        }
+        Elem<T>::store8(dx + p * ld_dx + v * 8, o);
+    }
+    // lanes l, l+cv, l+2cv ... share a channel vector: butterfly over the lane bits above log2(cv)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int c = 0; c < COUT; ++c) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = acc[c][j];
+            for (int o = 32; o >= cv; o >>= 1) t += __shfl_xor(t, o, 64);
+            acc[c][j] = t;
+        }
+        float t = db[c];
+        for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o, 64);
+        db[c] = t;
+    }
+    if (lane < cv) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[wv][lane][c * 8 + j] = acc[c][j];
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) dbs[wv][c] = db[c];
+    }
+    __syncthreads();
+    float* out = ws + (int64_t)blockIdx.x * (COUT * Cin + COUT);
+    for (int t = threadIdx.x; t < COUT * Cin; t += kThreads) {
+        const int c = t / Cin, ci = t % Cin;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kThreads / 64; ++k) s += red[k][ci / 8][c * 8 + (ci & 7)];
+        out[t] = s;
+    }
+    if (threadIdx.x < COUT) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < kThreads / 64; ++k) s += dbs[k][threadIdx.x];
+        out[COUT * Cin + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void head_bwd_finalize_kernel(const float* __restrict__ ws, int nblocks, int per,
+                                                                     int split, float* __restrict__ dw,
+                                                                     float* __restrict__ db) {
+    const int t = blockIdx.x * kThreads + threadIdx.x;
+    if (t >= per) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += (double)ws[(int64_t)b * per + t];
+    if (t < split) dw[t] = (float)s;
+    else if (db) db[t - split] = (float)s;
+}
+
+// ------------------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                        float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                        float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThreads) {
+        float gi = g[i] * gscale;
+        if (wd != 0.f) gi += wd * p[i];
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        p[i] -= (lr / bc1) * (mi / denom);
+    }
+}
+
+static int stats_bpg(int64_t groups, int64_t M, int64_t C) {
+    // ~16 pixel rows of work per thread at least; cap total blocks near 4096
+    const int64_t rows = kThreads / (C / 8);
+    int64_t bpg = M / (rows * 16);
+    const int64_t cap = (4096 + groups - 1) / groups;
+    if (bpg > cap) bpg = cap;
+    if (bpg < 1) bpg = 1;
+    return (int)bpg;
+}
+
+static int check_act(const char* who, const void* p, int64_t ld, int64_t C, int dtype) {
+    if (!p) return fail(SEGK_EINVAL, "%s: null activation pointer", who);
+    if (dtype != SEGK_F32 && dtype != SEGK_BF16) return fail(SEGK_EINVAL, "%s: unknown dtype %d", who, dtype);
+    if (C <= 0 || C % 8 != 0) return fail(SEGK_ESHAPE, "%s: channel count %lld is not a positive multiple of 8", who, (long long)C);
+    if (ld < C) return fail(SEGK_ESHAPE, "%s: ld %lld < C %lld", who, (long long)ld, (long long)C);
+    if (!aligned16(p) || (ld * esize(dtype)) % 16 != 0) return fail(SEGK_EALIGN, "%s: pointer/ld not 16-byte aligned", who);
+    return SEGK_OK;
+}
+#define SEGK_CHECK_ACT(...)                          \
+    do {                                             \
+        int rc_ = check_act(__VA_ARGS__);            \
+        if (rc_ != SEGK_OK) return rc_;              \
+    } while (0)
+
+static int check_norm_c(const char* who, int64_t C) {
+    if (C % 8 != 0 || !is_pow2(C / 8) || C / 8 > kThreads) return fail(SEGK_ESHAPE, "%s: C/8 must be a power of two <= 256 (C=%lld)", who, (long long)C);
+    return SEGK_OK;
+}
+
+}  // namespace segk
+
+using namespace segk;
+
+extern "C" int segk_nchw_to_nhwc(const float* src, int64_t N, int64_t Cin, int64_t H, int64_t W, void* dst, int dst_dtype,
+                                 int64_t Cout, int64_t ld, int dev, void* stream) {
+    SEGK_REQUIRE(src && N > 0 && Cin > 0 && H > 0 && W > 0 && Cout >= Cin, SEGK_ESHAPE, "nchw_to_nhwc: bad shape");
+    SEGK_CHECK_ACT("nchw_to_nhwc", dst, ld, Cout, dst_dtype);
+    SEGK_HIP(use_device(dev));
+    const int64_t items = N * H * W * (Cout / 8);
+    SEGK_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0,
+                                                         (hipStream_t)stream, src, N, (int)Cin, H * W, (T*)dst, (int)Cout, ld));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_im2col3x3(const float* src, int64_t N, int64_t Cin, int64_t H, int64_t W, void* dst, int dst_dtype,
+                              int64_t Cout, int64_t ld, int dev, void* stream) {
+    SEGK_REQUIRE(src && N > 0 && Cin > 0 && H > 0 && W > 0 && Cout >= 9 * Cin, SEGK_ESHAPE, "im2col3x3: bad shape");
+    SEGK_CHECK_ACT("im2col3x3", dst, ld, Cout, dst_dtype);
+    SEGK_HIP(use_device(dev));
+    const int64_t items = N * H * W * (Cout / 8);
+    SEGK_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((im2col3x3_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0,
+                                                         (hipStream_t)stream, src, N, (int)Cin, (int)H, (int)W, (T*)dst, (int)Cout, ld));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" size_t segk_norm_workspace(int64_t groups, int64_t M, int64_t C) {
+    if (groups <= 0 || M <= 0 || C <= 0 || C % 8) return 0;
+    // block partials [groups][bpg][2][C] followed by the reduced backward sums [groups][C][2]
+    return align_up((size_t)groups * stats_bpg(groups, M, C) * 2 * C * sizeof(float), 256) +
+           align_up((size_t)groups * C * 2 * sizeof(float), 256);
+}
+
+extern "C" int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t groups, int64_t M, int64_t C, float eps,
+                               float* stats, float* running_mean, float* running_var, float momentum, void* workspace,
+                               size_t workspace_bytes, int dev, void* stream) {
+    SEGK_CHECK_ACT("norm_stats", x, ld, C, dtype);
+    if (int rc = check_norm_c("norm_stats", C)) return rc;
+    SEGK_REQUIRE(stats && workspace && groups > 0 && groups < 65536 && M > 0, SEGK_EINVAL, "norm_stats: bad arguments");
+    SEGK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SEGK_EINVAL, "norm_stats: running buffers come in pairs");
+    SEGK_REQUIRE(!running_mean || groups == 1, SEGK_EINVAL, "norm_stats: running buffers need groups == 1");
+    SEGK_REQUIRE(workspace_bytes >= segk_norm_workspace(groups, M, C), SEGK_EWORKSPACE, "norm_stats: workspace too small");
+    SEGK_HIP(use_device(dev));
+    hipStream_t st = (hipStream_t)stream;
+    const int bpg = stats_bpg(groups, M, C);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 0>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
+                                                     (const T*)x, ld, M, (int)C, bpg, (float*)workspace));
+    SEGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads), (unsigned)groups), dim3(kThreads), 0, st,
+                       (const float*)workspace, bpg, M, (int)C, eps, stats, running_mean, running_var, momentum);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_norm_eval_stats(const float* running_mean, const float* running_var, int64_t C, float eps, float* stats,
+                                    int dev, void* stream) {
+    SEGK_REQUIRE(running_mean && running_var && stats && C > 0, SEGK_EINVAL, "norm_eval_stats: bad arguments");
+    SEGK_HIP(use_device(dev));
+    hipLaunchKernelGGL(eval_stats_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
+                       running_mean, running_var, (int)C, eps, stats);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_norm_apply(int dtype, const void* x, int64_t ldx, int64_t groups, int64_t M, int64_t C, const float* stats,
+                               const float* gamma, const float* beta, int flags, void* y, int64_t ldy, int dev, void* stream) {
+    SEGK_CHECK_ACT("norm_apply(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("norm_apply(y)", y, ldy, C, dtype);
+    if (int rc = check_norm_c("norm_apply", C)) return rc;
+    SEGK_REQUIRE(stats && groups > 0 && groups < 65536 && M > 0, SEGK_EINVAL, "norm_apply: bad arguments");
+    SEGK_HIP(use_device(dev));
+    const int rows = kThreads / (int)(C / 8);
+    int64_t gx = (M + rows - 1) / rows;
+    const int64_t cap = (8192 + groups - 1) / groups;
+    if (gx > cap) gx = cap;
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_apply_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)x, ldx, M, (int)C, stats, gamma, beta, flags & 1,
+                                                     (T*)y, ldy));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const void* x, int64_t ldx, int64_t groups, int64_t M,
+                             int64_t C, const float* stats, const float* gamma, const float* beta, int flags, void* dx,
+                             int64_t ld_dx, float* dgamma, float* dbeta, float* dbias_out, void* workspace,
+                             size_t workspace_bytes, int dev, void* stream) {
+    SEGK_CHECK_ACT("norm_bwd(dy)", dy, ld_dy, C, dtype);
+    SEGK_CHECK_ACT("norm_bwd(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("norm_bwd(dx)", dx, ld_dx, C, dtype);
+    if (int rc = check_norm_c("norm_bwd", C)) return rc;
+    SEGK_REQUIRE(stats && workspace && groups > 0 && groups < 65536 && M > 0, SEGK_EINVAL, "norm_bwd: bad arguments");
+    SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "norm_bwd: dgamma/dbeta come in pairs");
+    SEGK_REQUIRE(!dgamma || groups == 1, SEGK_EINVAL, "norm_bwd: affine gradients need groups == 1");
+    SEGK_REQUIRE(workspace_bytes >= segk_norm_workspace(groups, M, C), SEGK_EWORKSPACE, "norm_bwd: workspace too small");
+    SEGK_HIP(use_device(dev));
+    hipStream_t st = (hipStream_t)stream;
+    const int bpg = stats_bpg(groups, M, C);
+    const int relu = flags & 1, accumulate = (flags >> 1) & 1, frozen = (flags >> 2) & 1;
+    float* part = (float*)workspace;
+    float* red = (float*)((char*)workspace + align_up((size_t)groups * bpg * 2 * C * sizeof(float), 256));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_partial_kernel<T>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
+                                                     (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, bpg, part));
+    SEGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads), (unsigned)groups), dim3(kThreads), 0, st,
+                       (const float*)part, bpg, (int)C, red, dgamma, dbeta, accumulate);
+    SEGK_LAUNCH_CHECK();
+    const int rows = kThreads / (int)(C / 8);
+    int64_t gx = (M + rows - 1) / rows;
+    const int64_t cap = (8192 + groups - 1) / groups;
+    if (gx > cap) gx = cap;
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0, st,
+                                                     (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, frozen,
+                                                     (const float*)red, (T*)dx, ld_dx));
+    SEGK_LAUNCH_CHECK();
+    if (dbias_out) {
+        // With batch statistics the gradient reaching the convolution in front of the norm sums to zero
+        // over the pixels of a group, so its bias gradient is identically zero.
+        SEGK_REQUIRE(!frozen, SEGK_EINVAL, "norm_bwd: bias gradient with frozen statistics: use segk_colsum on dx");
+        if (!accumulate) SEGK_HIP(hipMemsetAsync(dbias_out, 0, (size_t)C * sizeof(float), st));
+    }
+    return SEGK_OK;
+}
+
+extern "C" int segk_maxpool2x2_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C, void* y,
+                                   int64_t ldy, int dev, void* stream) {
+    SEGK_CHECK_ACT("maxpool_fwd(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("maxpool_fwd(y)", y, ldy, C, dtype);
+    SEGK_REQUIRE(N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SEGK_ESHAPE, "maxpool_fwd: H and W must be even (H=%lld W=%lld)", (long long)H, (long long)W);
+    SEGK_HIP(use_device(dev));
+    const int64_t items = N * (H / 2) * (W / 2) * (C / 8);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
+                                                     (const T*)x, ldx, N, (int)H, (int)W, (int)C, (T*)y, ldy));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_maxpool2x2_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t ld_dy, int64_t N, int64_t H,
+                                   int64_t W, int64_t C, void* dx, int64_t ld_dx, int flags, int dev, void* stream) {
+    SEGK_CHECK_ACT("maxpool_bwd(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("maxpool_bwd(dy)", dy, ld_dy, C, dtype);
+    SEGK_CHECK_ACT("maxpool_bwd(dx)", dx, ld_dx, C, dtype);
+    SEGK_REQUIRE(N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SEGK_ESHAPE, "maxpool_bwd: H and W must be even");
+    SEGK_HIP(use_device(dev));
+    const int64_t items = N * (H / 2) * (W / 2) * (C / 8);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
+                                                     (const T*)x, ldx, (const T*)dy, ld_dy, N, (int)H, (int)W, (int)C, (T*)dx, ld_dx,
+                                                     (flags >> 1) & 1));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_upsample2x_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
+                                   const float* stats, int flags, void* y, int64_t ldy, int dev, void* stream) {
+    SEGK_CHECK_ACT("upsample_fwd(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("upsample_fwd(y)", y, ldy, C, dtype);
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0, SEGK_ESHAPE, "upsample_fwd: bad shape");
+    SEGK_HIP(use_device(dev));
+    const int64_t items = N * 4 * H * W * (C / 8);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
+                                                     (const T*)x, ldx, N, (int)H, (int)W, (int)C, stats, flags & 1, (flags >> 2) & 1,
+                                                     (T*)y, ldy));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, const void* y, int64_t ldy, int64_t N, int64_t H,
+                                   int64_t W, int64_t C, int flags, void* dx, int64_t ld_dx, int dev, void* stream) {
+    SEGK_CHECK_ACT("upsample_bwd(dy)", dy, ld_dy, C, dtype);
+    SEGK_CHECK_ACT("upsample_bwd(dx)", dx, ld_dx, C, dtype);
+    if (flags & 1) SEGK_CHECK_ACT("upsample_bwd(y)", y, ldy, C, dtype);
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0, SEGK_ESHAPE, "upsample_bwd: bad shape");
+    SEGK_HIP(use_device(dev));
+    const int64_t items = N * H * W * (C / 8);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
+                                                     (const T*)dy, ld_dy, (const T*)y, ldy, N, (int)H, (int)W, (int)C, flags & 1,
+                                                     (flags >> 2) & 1, (T*)dx, ld_dx));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" size_t segk_colsum_workspace(int64_t P, int64_t C) {
+    if (P <= 0 || C <= 0 || C % 8) return 0;
+    return align_up((size_t)stats_bpg(1, P, C) * 2 * C * sizeof(float), 256);
+}
+
+extern "C" int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int64_t C, float* out, int flags, void* workspace,
+                           size_t workspace_bytes, int dev, void* stream) {
+    SEGK_CHECK_ACT("colsum", x, ld, C, dtype);
+    if (int rc = check_norm_c("colsum", C)) return rc;
+    SEGK_REQUIRE(out && workspace && P > 0, SEGK_EINVAL, "colsum: bad arguments");
+    SEGK_REQUIRE(workspace_bytes >= segk_colsum_workspace(P, C), SEGK_EWORKSPACE, "colsum: workspace too small");
+    SEGK_HIP(use_device(dev));
+    hipStream_t st = (hipStream_t)stream;
+    const int bpg = stats_bpg(1, P, C);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 1>), dim3(bpg, 1), dim3(kThreads), 0, st, (const T*)x, ld, P,
+                                                     (int)C, bpg, (float*)workspace));
+    SEGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+                       (const float*)workspace, bpg, (int)C, out, (flags >> 1) & 1);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t P, int64_t C,
+                               int flags, int dev, void* stream) {
+    SEGK_CHECK_ACT("copy_slice(src)", src, ld_src, C, dtype);
+    SEGK_CHECK_ACT("copy_slice(dst)", dst, ld_dst, C, dtype);
+    SEGK_REQUIRE(P > 0, SEGK_ESHAPE, "copy_slice: bad shape");
+    SEGK_HIP(use_device(dev));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((copy_slice_kernel<T>), dim3(grid_for(P * (C / 8))), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)src, ld_src, (T*)dst, ld_dst, P, (int)C, (flags >> 1) & 1));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_head1x1_fwd(int dtype, const void* x, int64_t ld, int64_t Cin, int64_t N, int64_t HW, const float* w,
+                                const float* bias, int64_t Cout, float* logits, int dev, void* stream) {
+    SEGK_CHECK_ACT("head1x1_fwd", x, ld, Cin, dtype);
+    SEGK_REQUIRE(w && logits && N > 0 && HW > 0, SEGK_EINVAL, "head1x1_fwd: bad arguments");
+    SEGK_REQUIRE(Cout >= 1 && Cout <= kHeadMaxOut && Cin <= 1024, SEGK_ESHAPE, "head1x1_fwd: Cout must be 1..8 (got %lld)", (long long)Cout);
+    SEGK_HIP(use_device(dev));
+    const size_t smem = (size_t)(Cout * Cin + Cout) * sizeof(float);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid_for(N * HW, 4096)), dim3(kThreads), smem,
+                                                     (hipStream_t)stream, (const T*)x, ld, (int)Cin, N, HW, w, bias, (int)Cout, logits));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+static int head_bwd_blocks(int64_t Cin, int64_t N, int64_t HW) { return grid_for(N * HW * (Cin / 8), 1024); }
+
+extern "C" size_t segk_head1x1_bwd_workspace(int64_t Cin, int64_t Cout, int64_t N, int64_t HW) {
+    if (Cin <= 0 || Cout <= 0 || N <= 0 || HW <= 0) return 0;
+    return align_up((size_t)head_bwd_blocks(Cin, N, HW) * (Cout * Cin + Cout) * sizeof(float), 256);
+}
+
+template <typename T>
+static int launch_head_bwd(int Cout, dim3 grid, hipStream_t st, const void* x, int64_t ld, int Cin, int64_t N, int64_t HW,
+                           const float* w, const float* dlogits, void* dx, int64_t ld_dx, int relu_mask, float* ws) {
+#define SEGK_HB(K)                                                                                                            \
+    case K:                                                                                                                   \
+        hipLaunchKernelGGL((head_bwd_kernel<T, K>), grid, dim3(kThreads), 0, st, (const T*)x, ld, Cin, N, HW, w, dlogits, (T*)dx, \
+                           ld_dx, relu_mask, ws);                                                                             \
+        break;
+    switch (Cout) {
+        SEGK_HB(1) SEGK_HB(2) SEGK_HB(3) SEGK_HB(4) SEGK_HB(5) SEGK_HB(6) SEGK_HB(7) SEGK_HB(8)
+        default: return fail(SEGK_ESHAPE, "head1x1_bwd: Cout must be 1..8");
+    }
+#undef SEGK_HB
+    return SEGK_OK;
+}
+
+extern "C" int segk_head1x1_bwd(int dtype, const void* x, int64_t ld, int64_t Cin, int64_t N, int64_t HW, const float* w,
+                                int64_t Cout, const float* dlogits, void* dx, int64_t ld_dx, int relu_mask, float* dw, float* db,
+                                void* workspace, size_t workspace_bytes, int dev, void* stream) {
+    SEGK_CHECK_ACT("head1x1_bwd(x)", x, ld, Cin, dtype);
+    SEGK_CHECK_ACT("head1x1_bwd(dx)", dx, ld_dx, Cin, dtype);
+    SEGK_REQUIRE(w && dlogits && dw && workspace && N > 0 && HW > 0, SEGK_EINVAL, "head1x1_bwd: bad arguments");
+    SEGK_REQUIRE(Cin == 32 || Cin == 64, SEGK_ESHAPE, "head1x1_bwd: Cin must be 32 or 64 (got %lld)", (long long)Cin);
+    SEGK_REQUIRE(workspace_bytes >= segk_head1x1_bwd_workspace(Cin, Cout, N, HW), SEGK_EWORKSPACE, "head1x1_bwd: workspace too small");
+    SEGK_HIP(use_device(dev));
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = head_bwd_blocks(Cin, N, HW);
+    int rc = SEGK_OK;
+    SEGK_DISPATCH_DTYPE(dtype, T, rc = launch_head_bwd<T>((int)Cout, dim3(nb), st, x, ld, (int)Cin, N, HW, w, dlogits, dx, ld_dx,
+                                                          relu_mask, (float*)workspace));
+    if (rc != SEGK_OK) return rc;
+    SEGK_LAUNCH_CHECK();
+    const int per = (int)(Cout * Cin + Cout);
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3((per + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)workspace, nb,
+                       per, (int)(Cout * Cin), dw, db);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int64_t step, float grad_scale, int dev, void* stream) {
+    SEGK_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, SEGK_EINVAL, "adam_step: bad arguments");
+    SEGK_HIP(use_device(dev));
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
+                       lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}

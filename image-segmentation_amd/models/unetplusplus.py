@@ -1,0 +1,101 @@
+"""Nested U-Net (UNet++), MI355X-native.
+
+Constructor signatures, attribute names and state_dict layout of the reference
+(/root/reference/models/unetplusplus.py: conv_block_nested :6-25, Nested_UNet :27-82).  The dense skip
+concatenations of :64-79 are never materialised: every node x[i][j] is written by its producer into
+a per-resolution NHWC buffer [x[i][0] | x[i][1] | ...], a consumer convolution reads a prefix of that
+buffer as its first input segment and the up-sampled deeper node as its second.
+"""
+import torch
+from torch import nn
+
+from segk.net import SegkBlock, SegkNet
+from segk.ops import Act
+
+_WIDTHS = (64, 128, 256, 512, 1024)
+
+
+class conv_block_nested(SegkBlock):
+    """(conv3x3 + bias -> BatchNorm -> ReLU) twice."""
+
+    def __init__(self, in_ch, mid_ch, out_ch):
+        super().__init__()
+        self.activation = nn.ReLU(inplace=True)
+        self.conv1 = nn.Conv2d(in_ch, mid_ch, kernel_size=3, padding=1, bias=True)
+        self.bn1 = nn.BatchNorm2d(mid_ch)
+        self.conv2 = nn.Conv2d(mid_ch, out_ch, kernel_size=3, padding=1, bias=True)
+        self.bn2 = nn.BatchNorm2d(out_ch)
+
+    def _forward_host(self, x):
+        x = self.activation(self.bn1(self.conv1(x)))
+        return self.activation(self.bn2(self.conv2(x)))
+
+    def emit(self, rt, prefix, x, out=None, image=None):
+        """Append the block to a segk tape.  x: Var / concat description; image: raw NCHW input of the first block."""
+        zero = rt.training     # a bias in front of a batch-statistics norm has an identically zero gradient
+        if image is not None:
+            y = rt.conv_first(image, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero)
+        else:
+            y = rt.conv(x, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero)
+        h = rt.bn_relu(y, prefix + "bn1")
+        y = rt.conv(h, prefix + "conv2.weight", prefix + "conv2.bias", bias_grad_zero=zero)
+        return rt.bn_relu(y, prefix + "bn2", out=out)
+
+    def _emit_block(self, rt, v):
+        return self.emit(rt, "", v)
+
+
+class Nested_UNet(SegkNet):
+    def __init__(self, in_ch=1, out_ch=3):
+        super().__init__()
+        f = _WIDTHS
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.Up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
+        # registration order = the reference's, so state_dict key order matches
+        for i in range(5):
+            setattr(self, f"conv{i}_0", conv_block_nested(in_ch if i == 0 else f[i - 1], f[i], f[i]))
+        for j in range(1, 5):
+            for i in range(5 - j):
+                setattr(self, f"conv{i}_{j}", conv_block_nested(f[i] * j + f[i + 1], f[i], f[i]))
+        self.final = nn.Conv2d(f[0], out_ch, kernel_size=1)
+
+    @staticmethod
+    def _schedule():
+        """Nodes in the reference's evaluation order: after backbone node (i,0) the anti-diagonal it completes."""
+        for i in range(5):
+            yield i, 0
+            for j in range(1, i + 1):
+                yield i - j, j
+
+    def _forward_host(self, x):
+        node = {}
+        for i, j in self._schedule():
+            block = getattr(self, f"conv{i}_{j}")
+            if j == 0:
+                node[i, 0] = block(x if i == 0 else self.pool(node[i - 1, 0]))
+            else:
+                node[i, j] = block(torch.cat([node[i, k] for k in range(j)] + [self.Up(node[i + 1, j - 1])], 1))
+        return self.final(node[0, 4])
+
+    def _emit(self, rt, x):
+        N, cin, H, W = x.shape
+        if H % 16 or W % 16:
+            raise RuntimeError(f"Nested_UNet needs H and W divisible by 16 (four 2x2 pools), got {H}x{W}")
+        f = _WIDTHS
+        # level i keeps nodes j = 0 .. 3-i side by side (the ones later convolutions concatenate)
+        level = {i: rt.new(N, H >> i, W >> i, f[i] * (4 - i)).buf for i in range(4)}
+        node = {}
+        for i, j in self._schedule():
+            block = getattr(self, f"conv{i}_{j}")
+            out = Act(level[i], f[i] * j, f[i]) if (i < 4 and j < 4 - i) else None
+            if j == 0:
+                if i == 0 and 9 * cin <= 32:
+                    node[0, 0] = block.emit(rt, "conv0_0.", None, out=out, image=x)
+                elif i == 0:
+                    node[0, 0] = block.emit(rt, "conv0_0.", rt.input(x), out=out)
+                else:
+                    node[i, 0] = block.emit(rt, f"conv{i}_0.", rt.pool(node[i - 1, 0]), out=out)
+            else:
+                up = rt.up(node[i + 1, j - 1], align=True)
+                node[i, j] = block.emit(rt, f"conv{i}_{j}.", ([node[i, k] for k in range(j)], up), out=out)
+        return rt.head(node[0, 4], "final.weight", "final.bias")

@@ -1,0 +1,308 @@
+"""Layer-granular tape that runs a network's forward and backward as explicit kernel launches.
+
+A model's `forward` describes itself once per call through the helpers below (conv, bn_relu, pool,
+in_up_relu, ...).  Each helper launches the forward kernels immediately and, when gradients are
+needed, records a closure that launches the matching backward kernels; `Tape.backward` replays the
+closures in reverse.  There is no graph compiler: the tape is the schedule.
+
+Gradient buffers mirror activation buffers (same NHWC shape), so a tensor that lives in a channel
+slice of a concat buffer receives its gradient in the same slice of the mirrored buffer and the
+data-gradient of the convolution that reads the whole concat buffer fills all slices at once.
+"""
+import torch
+
+from . import ops
+from .ops import Act
+
+
+class Var:
+    """An activation view plus the bookkeeping of its gradient."""
+    __slots__ = ("act", "ready", "relu_fused")
+
+    def __init__(self, act, relu_fused=False):
+        self.act = act
+        self.ready = False            # gradient slice has been written at least once
+        self.relu_fused = relu_fused  # act = relu(conv): the producer's ReLU backward is applied by the consumer
+
+
+class Runtime:
+    def __init__(self, params, buffers, dtype, device, training, need_grad, grad_sink=None, grad_alloc=None):
+        self.p, self.b = params, buffers        # name -> tensor
+        self.dtype, self.device = dtype, device
+        self.training, self.need_grad = training, need_grad
+        self.tape = []
+        self.grads = {}
+        self._gradbufs = {}
+        self._keep = []                         # keeps activation buffers alive until backward
+        self.grad_sink = grad_sink              # optional callback(name, tensor) fired as soon as a gradient is final
+        self.grad_alloc = grad_alloc            # optional callback(name, like) -> tensor to write the gradient into
+
+    # ---------------------------------------------------------------- buffers
+    def new(self, N, H, W, C, zero=False):
+        return Act.empty(N, H, W, C, self.dtype, self.device, zero=zero)
+
+    def grad_of(self, act):
+        """Gradient view mirroring `act` (allocated per underlying buffer on first use)."""
+        key = id(act.buf)
+        g = self._gradbufs.get(key)
+        if g is None:
+            g = torch.empty_like(act.buf)
+            self._gradbufs[key] = g
+            self._keep.append(act.buf)
+        return Act(g, act.c0, act.C)
+
+    def alloc_grad(self, name, like):
+        """fp32 tensor that receives the gradient of parameter `name` (a view into a flat all-reduce
+        bucket when a data-parallel wrapper installed `grad_alloc`)."""
+        if self.grad_alloc is not None:
+            return self.grad_alloc(name, like)
+        return torch.empty_like(like, dtype=torch.float32)
+
+    def _emit(self, name, tensor):
+        self.grads[name] = tensor
+        if self.grad_sink is not None:
+            self.grad_sink(name, tensor)
+
+    def record(self, fn):
+        if self.need_grad:
+            self.tape.append(fn)
+
+    def backward_keep(self):
+        for fn in reversed(self.tape):
+            fn()
+        self.tape = []
+
+    def release(self):
+        self._gradbufs = {}
+        self._keep = []
+
+    def backward(self):
+        self.backward_keep()
+        self.release()
+
+    def input(self, x):
+        """NCHW tensor -> NHWC activation Var (layout conversion by a torch copy: boundary plumbing)."""
+        return Var(Act.from_nchw(x.detach(), self.dtype))
+
+    # ---------------------------------------------------------------- packed weights
+    def _pack(self, w4d, seg0=0):
+        return ops.conv_pack(w4d, self.dtype, seg0=seg0, want_fwd=True, want_bwd=self.need_grad)
+
+    # ---------------------------------------------------------------- layers
+    def conv_first(self, x, wname, bname, bias_grad_zero=False):
+        """3x3 convolution of a few-channel NCHW fp32 image, run as a 1x1 convolution over its 3x3 patch
+        image (one K-row of 9*Cin gathered values).  The output carries Cout rounded up to 8 channels
+        (extra ones are exactly zero).  No data gradient: the image does not require one."""
+        w = self.p[wname]
+        Cout, Cin = w.shape[0], w.shape[1]
+        cs = (Cout + 7) // 8 * 8
+        patches = ops.im2col3x3(x, self.dtype)
+        w1 = torch.zeros(cs, 9 * Cin, 1, 1, dtype=torch.float32, device=self.device)
+        w1[:Cout] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
+        wf, _ = ops.conv_pack(w1, self.dtype, want_bwd=False)
+        N, _, H, W = x.shape
+        y = Var(self.new(N, H, W, cs))
+        ops.conv_fwd(patches, wf, cs, y.act, taps=1, bias=self._bias(bname, cs))
+
+        def bwd():
+            dy = self.grad_of(y.act)
+            dw = torch.empty(cs, 9 * Cin, dtype=torch.float32, device=self.device)
+            ops.conv_wgrad(patches, dy, dw, taps=1, cin_real=9 * Cin)
+            g = self.alloc_grad(wname, w)
+            g.copy_(dw[:Cout].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2))
+            self._emit(wname, g)
+            if bname is not None:
+                gb = self.alloc_grad(bname, self.p[bname])
+                if bias_grad_zero:
+                    gb.zero_()
+                else:
+                    gb.copy_(ops.colsum(dy, torch.empty(cs, dtype=torch.float32, device=self.device))[:Cout])
+                self._emit(bname, gb)
+        self.record(bwd)
+        return y
+
+    def _bias(self, bname, cs=None):
+        if bname is None:
+            return None
+        b = self.p[bname].detach()
+        if cs is not None and cs != b.numel():
+            pb = torch.zeros(cs, dtype=torch.float32, device=self.device)
+            pb[:b.numel()] = b
+            return pb
+        return b
+
+    def conv(self, x, wname, bname=None, relu=False, out=None, bias_grad_zero=False, seg_vars=None, cin_real=None):
+        """3x3 convolution.  x: Var, or a list of Vars that tile one buffer contiguously (in-place concat),
+        or a pair (list_of_vars, Var) for a two-segment concat.  Returns the output Var."""
+        w = self.p[wname]
+        Cout, Cin = w.shape[0], w.shape[1]
+        segs = self._segments(x)
+        seg0 = segs[0][0].C if len(segs) == 2 else 0
+        wf, wb = self._pack(w.detach(), seg0=seg0)
+        a0 = segs[0][0]
+        N, H, W = a0.N, a0.H, a0.W
+        y = Var(out or self.new(N, H, W, Cout), relu_fused=relu)
+        xin = a0 if len(segs) == 1 else (segs[0][0], segs[1][0])
+        ops.conv_fwd(xin, wf, Cout, y.act, taps=9, bias=self._bias(bname), relu=relu)
+
+        def bwd():
+            dy = self.grad_of(y.act)
+            dw = self.alloc_grad(wname, w)
+            ops.conv_wgrad(xin, dy, dw, taps=9, cin_real=Cin)
+            self._emit(wname, dw)
+            if bname is not None:
+                db = self.alloc_grad(bname, self.p[bname])
+                if bias_grad_zero:
+                    db.zero_()
+                else:
+                    ops.colsum(dy, db)
+                self._emit(bname, db)
+            self._dgrad(segs, dy, wb, Cin)
+        self.record(bwd)
+        return y
+
+    def _segments(self, x):
+        """-> list of (covering Act, [member Vars])."""
+        def one(v):
+            if isinstance(v, Var):
+                return (v.act, [v])
+            members = list(v)
+            a = members[0].act
+            c = a.c0
+            for m in members:
+                assert m.act.buf is a.buf and m.act.c0 == c, "concat members must tile one buffer in order"
+                c += m.act.C
+            return (Act(a.buf, a.c0, c - a.c0), members)
+        if isinstance(x, tuple):
+            return [one(x[0]), one(x[1])]
+        return [one(x)]
+
+    def _dgrad(self, segs, dy, wb, Cin):
+        """Data gradient of a convolution into the gradient slices of its input segments."""
+        def mask_of(members):
+            fused = [m for m in members if m.relu_fused]
+            if not fused:
+                return None
+            assert len(members) == 1, "a fused-ReLU tensor must be a whole segment"
+            return members[0].act
+
+        def state(members):
+            r = [m.ready for m in members]
+            assert all(r) or not any(r), "mixed gradient readiness inside one concat segment"
+            return r[0]
+
+        if len(segs) == 1:
+            act, members = segs[0]
+            ops.conv_fwd(dy, wb, act.C, self.grad_of(act), taps=9, mask=mask_of(members), accumulate=state(members))
+            for m in members:
+                m.ready = True
+            return
+        tmp = self.new(dy.N, dy.H, dy.W, Cin)
+        ops.conv_fwd(dy, wb, Cin, tmp, taps=9)
+        c = 0
+        for act, members in segs:
+            assert mask_of(members) is None
+            ops.copy_slice(tmp.slice(c, act.C), self.grad_of(act), accumulate=state(members))
+            for m in members:
+                m.ready = True
+            c += act.C
+
+    def bn_relu(self, y, prefix, out=None, eps=1e-5, momentum=0.1):
+        """BatchNorm2d (+ReLU).  Training: batch statistics and running-buffer update; eval: running buffers."""
+        C = y.act.C
+        gamma, beta = self.p[prefix + ".weight"].detach(), self.p[prefix + ".bias"].detach()
+        stats = torch.empty(2 * C, dtype=torch.float32, device=self.device)
+        if self.training:
+            ops.norm_stats(y.act, 1, eps, stats, self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], momentum)
+            self.b[prefix + ".num_batches_tracked"].add_(1)
+        else:
+            ops.norm_eval_stats(self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], eps, stats)
+        a = Var(out or self.new(y.act.N, y.act.H, y.act.W, C))
+        ops.norm_apply(y.act, 1, stats, gamma, beta, True, a.act)
+        frozen = not self.training
+
+        def bwd():
+            da = self.grad_of(a.act)
+            dy = self.grad_of(y.act)
+            dg, db = self.alloc_grad(prefix + ".weight", gamma), self.alloc_grad(prefix + ".bias", beta)
+            ops.norm_bwd(da, y.act, 1, stats, gamma, beta, True, dy, dgamma=dg, dbeta=db, frozen=frozen)
+            y.ready = True
+            self._emit(prefix + ".weight", dg)
+            self._emit(prefix + ".bias", db)
+        self.record(bwd)
+        return a
+
+    def pool(self, a, out=None):
+        x = a.act
+        p = Var(out or self.new(x.N, x.H // 2, x.W // 2, x.C))
+        ops.maxpool_fwd(x, p.act)
+
+        def bwd():
+            ops.maxpool_bwd(x, self.grad_of(p.act), self.grad_of(x), accumulate=a.ready)
+            a.ready = True
+        self.record(bwd)
+        return p
+
+    def in_up_relu(self, y, out=None, eps=1e-5, upsample=True):
+        """InstanceNorm2d(affine=False) -> bilinear x2 (align_corners=False) -> ReLU, one pass over the output."""
+        x = y.act
+        stats = torch.empty(2 * x.N * x.C, dtype=torch.float32, device=self.device)
+        ops.norm_stats(x, x.N, eps, stats)
+        if upsample:
+            u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C))
+            ops.upsample_fwd(x, u.act, stats=stats, relu=True, align=False)
+        else:
+            u = Var(out or self.new(x.N, x.H, x.W, x.C))
+            ops.norm_apply(x, x.N, stats, None, None, True, u.act)
+
+        def bwd():
+            du = self.grad_of(u.act)
+            dy = self.grad_of(x)
+            if upsample:
+                dxh = self.new(x.N, x.H, x.W, x.C)
+                ops.upsample_bwd(du, u.act, dxh, relu=True, align=False)
+                ops.norm_bwd(dxh, x, x.N, stats, None, None, False, dy)
+            else:
+                ops.norm_bwd(du, x, x.N, stats, None, None, True, dy)
+            y.ready = True
+        self.record(bwd)
+        return u
+
+    def up(self, a, out=None, align=True):
+        """Plain bilinear x2 (models/unetplusplus.py:36)."""
+        x = a.act
+        u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C))
+        ops.upsample_fwd(x, u.act, stats=None, relu=False, align=align)
+
+        def bwd():
+            du = self.grad_of(u.act)
+            if a.ready:
+                tmp = self.new(x.N, x.H, x.W, x.C)
+                ops.upsample_bwd(du, None, tmp, relu=False, align=align)
+                ops.copy_slice(tmp, self.grad_of(x), accumulate=True)
+            else:
+                ops.upsample_bwd(du, None, self.grad_of(x), relu=False, align=align)
+            a.ready = True
+        self.record(bwd)
+        return u
+
+    def head(self, e, wname, bname):
+        """1x1 classification head -> NCHW fp32 logits (a torch tensor, the network output)."""
+        w, b = self.p[wname].detach(), self.p[bname].detach()
+        Cout = w.shape[0]
+        x = e.act
+        logits = torch.empty(x.N, Cout, x.H, x.W, dtype=torch.float32, device=self.device)
+        ops.head_fwd(x, w.reshape(Cout, -1).contiguous(), b, logits)
+        self._head = (e, w, wname, bname, logits)
+        return logits
+
+    def head_backward(self, dlogits):
+        e, w, wname, bname, _ = self._head
+        Cout = w.shape[0]
+        dl = dlogits.contiguous().float()
+        dw = self.alloc_grad(wname, w)
+        db = self.alloc_grad(bname, self.p[bname])
+        ops.head_bwd(e.act, w.reshape(Cout, -1).contiguous(), dl, self.grad_of(e.act), e.relu_fused, dw, db)
+        e.ready = True
+        self._emit(wname, dw)
+        self._emit(bname, db)

@@ -1,0 +1,213 @@
+"""Fused softmax + squared-Dice + focal loss on the GPU (autograd.Function over the C ABI) and the
+arg-max Dice metric.  CPU tensors are served by the same formulas in torch ops (`_host_*`)."""
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from .ops import dt, workspace
+from ._lib import call, query
+
+NO_SFT, ALL_CHANN, FOCAL_SUM = 1, 2, 4
+
+
+def _env(t):
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return dev, torch.cuda.current_stream(dev).cuda_stream
+
+
+class _DiceFocalFn(torch.autograd.Function):
+    """(logits, target) -> (dice_coefficient, focal_loss); one forward kernel computes the per-(n,c) sums both
+    losses need, one backward kernel writes dlogits for any mix of the two upstream gradients."""
+
+    @staticmethod
+    def forward(ctx, logits, target, gamma, alpha, flags, want_map):
+        _lib.lib()
+        z = logits.contiguous()
+        if z.dtype not in (torch.float32, torch.bfloat16):
+            z = z.float()
+        N, C = z.shape[0], z.shape[1]
+        HW = z[0, 0].numel()
+        labels = hot = None
+        if target.dtype == torch.int64:
+            labels = target.contiguous()
+        else:
+            hot = target.contiguous().float()
+        al = None if alpha is None else alpha.to(device=z.device, dtype=torch.float32).contiguous()
+        dev, st = _env(z)
+        sums = torch.empty(N * C * 4, dtype=torch.float32, device=z.device)
+        iflags = torch.empty(N, dtype=torch.int32, device=z.device)
+        scalars = torch.empty(4, dtype=torch.float32, device=z.device)
+        fmap = torch.empty(z.shape, dtype=torch.float32, device=z.device) if want_map else None
+        ws = workspace(query("segk_dice_focal_workspace", N, C, HW), z.device)
+        p = lambda t: None if t is None else t.data_ptr()
+        call("segk_dice_focal_fwd", z.data_ptr(), dt(z.dtype), p(labels), p(hot), N, C, HW, float(gamma), p(al), flags,
+             sums.data_ptr(), iflags.data_ptr(), p(fmap), ws.data_ptr(), ws.numel(), dev, st)
+        call("segk_dice_focal_finalize", sums.data_ptr(), iflags.data_ptr(), N, C, HW, flags, scalars.data_ptr(), dev, st)
+        ctx.save_for_backward(z, labels if labels is not None else hot, sums, iflags, scalars)
+        ctx.meta = (N, C, HW, float(gamma), al, flags, labels is not None, logits.dtype)
+        ctx.set_materialize_grads(False)
+        outs = (scalars[0], scalars[1])
+        if want_map:
+            ctx.mark_non_differentiable(fmap)
+            return outs + (fmap,)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_dice, g_focal, *unused):
+        z, tgt, sums, iflags, scalars = ctx.saved_tensors
+        N, C, HW, gamma, al, flags, is_labels, in_dtype = ctx.meta
+        gs = torch.zeros(2, dtype=torch.float32, device=z.device)
+        if g_dice is not None:
+            gs[0] = -g_dice.float()          # the kernel differentiates the loss 1 - coefficient
+        if g_focal is not None:
+            gs[1] = g_focal.float()
+        dz = torch.empty_like(z)
+        dev, st = _env(z)
+        p = lambda t: None if t is None else t.data_ptr()
+        call("segk_dice_focal_bwd", z.data_ptr(), dt(z.dtype), p(tgt) if is_labels else None, None if is_labels else p(tgt),
+             N, C, HW, gamma, p(al), flags, sums.data_ptr(), iflags.data_ptr(), scalars.data_ptr(), gs.data_ptr(),
+             dz.data_ptr(), dev, st)
+        return dz.to(in_dtype), None, None, None, None, None
+
+
+def _as_square_labels(act):
+    # the reference reshapes with shape[2] twice (loss/dice.py:48): non-square targets raise exactly there
+    return act.view(act.shape[0], 1, act.shape[2], act.shape[2])
+
+
+def dice_focal(pred, target, gamma=2.0, alpha=None, no_sft=False, is_all_chann=False, focal_sum=False, want_map=False):
+    flags = (NO_SFT if no_sft else 0) | (ALL_CHANN if is_all_chann else 0) | (FOCAL_SUM if focal_sum else 0)
+    return _DiceFocalFn.apply(pred, target, gamma, alpha, flags, want_map)
+
+
+# ------------------------------------------------------------------------------------ public: Dice
+def dice_coefficient_sq(probs, act, ignore_onlybg=False, no_sft=False, is_all_chann=False):
+    if not probs.is_cuda:
+        return _host_dice_sq(probs, act, no_sft, is_all_chann)
+    if act.dim() != 4:
+        sq = _as_square_labels(act)
+        if sq.dtype != torch.int64:
+            raise RuntimeError("scatter(): Expected dtype int64 for index")
+        target = sq.view(sq.shape[0], sq.shape[2], sq.shape[3])
+    else:
+        target = act.float()
+    coeff, _ = dice_focal(probs, target, no_sft=no_sft, is_all_chann=is_all_chann)
+    return coeff
+
+
+def dice_loss_sq(pred, act, no_sft=False, is_all_chann=False):
+    return 1 - dice_coefficient_sq(pred, act, no_sft=no_sft, is_all_chann=is_all_chann)
+
+
+def dice_coefficient(probs, act, is_list_bat=False, nosft=False, channelcnt=None, is_all_chann=False):
+    """Arg-max Dice (validation metric, not differentiable)."""
+    if not probs.is_cuda or act.dim() == 4 or probs.dim() != 4 or (channelcnt and channelcnt != probs.shape[1]):
+        if probs.is_cuda and (act.dim() == 4 or probs.dim() != 4 or channelcnt):
+            raise NotImplementedError("the HIP metric kernel takes [N,C,H,W] scores and [N,H,W] integer labels")
+        return _host_dice_metric(probs, act, is_list_bat, nosft, channelcnt, is_all_chann)
+    _lib.lib()
+    sq = _as_square_labels(act)
+    if sq.dtype != torch.int64:
+        raise RuntimeError("scatter(): Expected dtype int64 for index")
+    z = probs.detach().contiguous()
+    if z.dtype not in (torch.float32, torch.bfloat16):
+        z = z.float()
+    N, C = z.shape[0], z.shape[1]
+    HW = z[0, 0].numel()
+    counts = torch.empty(N, C, 3, dtype=torch.float32, device=z.device)
+    iflags = torch.empty(N, dtype=torch.int32, device=z.device)
+    dev, st = _env(z)
+    call("segk_argmax_dice", z.data_ptr(), dt(z.dtype), sq.contiguous().data_ptr(), N, C, HW, None, counts.data_ptr(),
+         iflags.data_ptr(), dev, st)
+    dice = (2 * counts[..., 0] + 1) / (counts[..., 1] + counts[..., 2] + 1)
+    kept = dice if (is_all_chann or C == 1) else dice[:, 1:]
+    if is_list_bat:
+        return kept
+    sel = iflags.bool()
+    nsel = sel.sum()
+    div = torch.where(nsel > 0, nsel * kept.shape[1], torch.tensor(kept.numel(), device=z.device))
+    return (kept * sel[:, None]).sum() / div
+
+
+def argmax_mask(logits):
+    """uint8 arg-max mask [N,H,W] of NCHW scores (first maximum wins, like torch.argmax)."""
+    _lib.lib()
+    z = logits.detach().contiguous()
+    N, C = z.shape[0], z.shape[1]
+    HW = z[0, 0].numel()
+    mask = torch.empty((N,) + tuple(z.shape[2:]), dtype=torch.uint8, device=z.device)
+    counts = torch.empty(N, C, 3, dtype=torch.float32, device=z.device)
+    iflags = torch.empty(N, dtype=torch.int32, device=z.device)
+    labels = torch.zeros(N, HW, dtype=torch.int64, device=z.device)
+    dev, st = _env(z)
+    call("segk_argmax_dice", z.data_ptr(), dt(z.dtype), labels.data_ptr(), N, C, HW, mask.data_ptr(), counts.data_ptr(),
+         iflags.data_ptr(), dev, st)
+    return mask
+
+
+# ------------------------------------------------------------------------------------ public: focal
+def focal_loss_with_logits(p, t, gamma=2., alpha=None, reduction='elementwise_mean'):
+    if not p.is_cuda:
+        return _host_focal(p, t, gamma, alpha, reduction)
+    if t.dtype != torch.int64:
+        raise RuntimeError(f"expected scalar type Long but found {t.dtype}")
+    if reduction not in ('elementwise_mean', 'none', 'sum'):
+        raise ValueError('Reduction parameter unknown.')
+    if reduction == 'none':
+        out = dice_focal(p, t, gamma=gamma, alpha=alpha, want_map=True)
+        return out[2].to(p.dtype)
+    _, loss = dice_focal(p, t, gamma=gamma, alpha=alpha, focal_sum=(reduction == 'sum'))
+    return loss.to(p.dtype)
+
+
+# ------------------------------------------------------------------------------------ CPU tensors
+def _host_onehot(labels, n_classes):
+    idx = _as_square_labels(labels)
+    return torch.zeros(idx.shape[0], n_classes, idx.shape[2], idx.shape[3]).scatter(1, idx, 1)
+
+
+def _host_fg_mean(table, act, keep_all, need_multi):
+    kept = table if (keep_all or table.shape[1] == 1) else table[:, 1:]
+    rows = torch.unique(torch.nonzero(act, as_tuple=True)[0])
+    denom = kept.numel()
+    if len(rows) and (table.shape[1] > 1 or not need_multi):
+        denom = len(rows) * kept.shape[1]
+    return kept[rows].sum() / denom, kept
+
+
+def _host_dice_sq(scores, act, no_sft, keep_all):
+    g = act if act.dim() == 4 else _host_onehot(act, scores.shape[1])
+    p = scores if no_sft else scores.softmax(1)
+    table = (2 * (p * g).sum((2, 3)) + 1) / ((p * p).sum((2, 3)) + (g * g).sum((2, 3)) + 1)
+    return _host_fg_mean(table, act, keep_all, True)[0]
+
+
+def _host_dice_metric(scores, act, as_list, nosft, channelcnt, keep_all):
+    if act.dim() != 4:
+        channelcnt = channelcnt or scores.shape[-3]
+        g = _host_onehot(act, channelcnt)
+    else:
+        g = act
+    p = scores if nosft else scores.softmax(1)
+    if p.dim() != 3:
+        p = p.argmax(1)
+    p = p.unsqueeze(1)
+    ph = torch.zeros(p.shape[0], channelcnt, *p.shape[-2:]).scatter(1, p.long(), 1)
+    table = (2 * (ph * g).sum((2, 3)) + 1) / (ph.sum((2, 3)) + g.sum((2, 3)) + 1)
+    mean, kept = _host_fg_mean(table, act, keep_all, False)
+    return kept if as_list else mean
+
+
+def _host_focal(p, t, gamma, alpha, reduction):
+    ce = F.cross_entropy(p, t, weight=alpha, reduction='none').unsqueeze(1)
+    q = p.softmax(1)
+    is_t = torch.zeros_like(q, dtype=torch.bool).scatter_(1, t.unsqueeze(1), True)
+    weight = (1 - torch.where(is_t, q, 1 - q)).pow(gamma)
+    val = weight * ce
+    if reduction == 'elementwise_mean':
+        return val.mean()
+    if reduction == 'sum':
+        return val.sum()
+    if reduction == 'none':
+        return val
+    raise ValueError('Reduction parameter unknown.')

@@ -1,0 +1,118 @@
+"""nn.Module base that routes CUDA tensors through the segk tape inside one autograd.Function.
+
+Subclasses provide `_emit(rt, x) -> logits` (the network expressed with segk.engine.Runtime helpers) and
+`_forward_host(x)` (the plain torch.nn path that serves CPU tensors, e.g. the reference's
+`saved_model.cpu()` inference in result_utils/save_img.py:122-143).  GPU tensors never take the torch
+path: without libsegk.so the forward raises.
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import _lib
+from .engine import Runtime
+
+_DEFAULT_DTYPE = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[
+    os.environ.get("SEGK_DTYPE", "fp32").lower()]
+
+
+def set_default_compute_dtype(dtype):
+    """Arithmetic type of the HIP kernels for modules that did not choose one: torch.float32 (parity with
+    the fp32 reference, default) or torch.bfloat16 (matrix-core rate; fp32 accumulation and statistics)."""
+    global _DEFAULT_DTYPE
+    assert dtype in (torch.float32, torch.bfloat16)
+    _DEFAULT_DTYPE = dtype
+
+
+class _TapeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, net, x, need_grad, *params):
+        names = net._segk_param_names
+        dtype = net.compute_dtype()
+        hooks = getattr(net, "_segk_grad_hooks", None) or (None, None)
+        rt = Runtime(dict(zip(names, params)), dict(net.named_buffers()), dtype, x.device, net.training, need_grad,
+                     grad_sink=hooks[0], grad_alloc=hooks[1])
+        logits = net._emit(rt, x)
+        ctx.rt, ctx.names = rt, names
+        ctx.set_materialize_grads(False)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        rt = ctx.rt
+        if dlogits is None:
+            return (None, None, None) + tuple(None for _ in ctx.names)
+        rt.head_backward(dlogits)
+        rt.backward()
+        grads = tuple(rt.grads.get(n) if ctx.needs_input_grad[3 + i] else None for i, n in enumerate(ctx.names))
+        ctx.rt = None
+        return (None, None, None) + grads
+
+
+class SegkNet(nn.Module):
+    _segk_dtype = None
+
+    def set_compute_dtype(self, dtype):
+        assert dtype in (None, torch.float32, torch.bfloat16)
+        self._segk_dtype = dtype
+        return self
+
+    def compute_dtype(self):
+        if self._segk_dtype is not None:
+            return self._segk_dtype
+        if torch.is_autocast_enabled():
+            return torch.bfloat16
+        return _DEFAULT_DTYPE
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return self._forward_host(x)
+        _lib.lib()   # raises if the HIP library is absent
+        named = list(self.named_parameters())
+        self._segk_param_names = [n for n, _ in named]
+        params = [p for _, p in named]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _TapeFn.apply(self, x, need_grad, *params)
+
+
+class _BlockFn(torch.autograd.Function):
+    """A stand-alone building block (decoder block, double-conv block) on NCHW tensors: layout conversion at
+    both ends, data gradient returned for the input."""
+
+    @staticmethod
+    def forward(ctx, block, x, need_grad, *params):
+        names = block._segk_param_names
+        rt = Runtime(dict(zip(names, params)), dict(block.named_buffers()), block.compute_dtype(), x.device, block.training,
+                     need_grad)
+        v = rt.input(x)
+        out = block._emit_block(rt, v)
+        ctx.rt, ctx.names, ctx.v, ctx.out = rt, names, v, out
+        return out.act.nchw().float().contiguous()
+
+    @staticmethod
+    def backward(ctx, dout):
+        rt = ctx.rt
+        rt.grad_of(ctx.out.act).nchw().copy_(dout)
+        rt.backward_keep()
+        dx = rt.grad_of(ctx.v.act).nchw().float().contiguous() if (ctx.needs_input_grad[1] and ctx.v.ready) else None
+        rt.release()
+        grads = tuple(rt.grads.get(n) if ctx.needs_input_grad[3 + i] else None for i, n in enumerate(ctx.names))
+        ctx.rt = None
+        return (None, dx, None) + grads
+
+
+class SegkBlock(SegkNet):
+    """Base of blocks that are also usable on their own: CUDA tensors run `_emit_block` on a private tape."""
+
+    def forward(self, x):
+        if not x.is_cuda:
+            return self._forward_host(x)
+        _lib.lib()
+        if x.shape[1] % 8:
+            raise NotImplementedError("stand-alone HIP blocks take a channel count that is a multiple of 8")
+        named = list(self.named_parameters())
+        self._segk_param_names = [n for n, _ in named]
+        params = [p for _, p in named]
+        need_grad = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        return _BlockFn.apply(self, x, need_grad, *params)

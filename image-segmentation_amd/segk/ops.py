@@ -1,0 +1,261 @@
+"""Tensor-level wrappers over the C ABI: shape bookkeeping only, no arithmetic.
+
+Activations are `Act` views: channels [c0, c0+C) of an NHWC buffer [N,H,W,ld].  Producers write
+straight into a channel slice of a wider buffer, which is how torch.cat of the reference
+(models/unetvgg.py:99-103) disappears.
+"""
+import torch
+
+from . import _lib
+from ._lib import SEGK_BF16, SEGK_F32, call, query
+
+_DT = {torch.float32: SEGK_F32, torch.bfloat16: SEGK_BF16}
+RELU, ACCUM, ALIGN, FROZEN = 1, 2, 4, 4   # flag bits (ALIGN: upsample; FROZEN: norm_bwd)
+
+
+def dt(dtype):
+    try:
+        return _DT[dtype]
+    except KeyError:
+        raise TypeError(f"segk computes in float32 or bfloat16, not {dtype}") from None
+
+
+def krow(dtype):
+    return 64 if dtype == torch.bfloat16 else 32
+
+
+class Act:
+    """View of channels [c0, c0+C) of the NHWC buffer `buf` ([N,H,W,ld], contiguous)."""
+    __slots__ = ("buf", "c0", "C")
+
+    def __init__(self, buf, c0=0, C=None):
+        assert buf.dim() == 4 and buf.is_contiguous()
+        self.buf, self.c0 = buf, c0
+        self.C = buf.shape[3] - c0 if C is None else C
+        assert 0 <= c0 and c0 + self.C <= buf.shape[3]
+
+    N = property(lambda s: s.buf.shape[0])
+    H = property(lambda s: s.buf.shape[1])
+    W = property(lambda s: s.buf.shape[2])
+    ld = property(lambda s: s.buf.shape[3])
+    dtype = property(lambda s: s.buf.dtype)
+    device = property(lambda s: s.buf.device)
+    P = property(lambda s: s.buf.shape[0] * s.buf.shape[1] * s.buf.shape[2])
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.c0 * self.buf.element_size()
+
+    def slice(self, c0, C):
+        return Act(self.buf, self.c0 + c0, C)
+
+    def nchw(self):
+        """Logical NCHW tensor (a strided view) for tests and debugging."""
+        return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
+
+    @staticmethod
+    def empty(N, H, W, C, dtype, device, zero=False):
+        mk = torch.zeros if zero else torch.empty
+        return Act(mk((N, H, W, C), dtype=dtype, device=device))
+
+    @staticmethod
+    def from_nchw(x, dtype=None):
+        """Test helper: copy a logical NCHW tensor into a fresh NHWC buffer."""
+        return Act(x.permute(0, 2, 3, 1).contiguous().to(dtype or x.dtype))
+
+
+def _env(t):
+    dev = t.device.index if t.device.index is not None else torch.cuda.current_device()
+    return dev, torch.cuda.current_stream(dev).cuda_stream
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device):
+    """Per-device scratch buffer; every kernel that uses it runs on the current stream, so successive
+    uses are ordered."""
+    key = (device.type, device.index)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------ layout
+def im2col3x3(x, dtype):
+    """[N,Cin,H,W] fp32 -> NHWC patch image with one K-row of channels (9*Cin real ones)."""
+    N, Cin, H, W = x.shape
+    C = krow(dtype)
+    assert 9 * Cin <= C, "im2col path is for few-channel inputs"
+    x = x.contiguous().float()
+    out = Act.empty(N, H, W, C, dtype, x.device)
+    dev, st = _env(x)
+    call("segk_im2col3x3", x.data_ptr(), N, Cin, H, W, out.ptr, dt(dtype), C, out.ld, dev, st)
+    return out
+
+
+def nchw_to_nhwc(x, dtype, C=None):
+    N, Cin, H, W = x.shape
+    C = C or (Cin + 7) // 8 * 8
+    x = x.contiguous().float()
+    out = Act.empty(N, H, W, C, dtype, x.device)
+    dev, st = _env(x)
+    call("segk_nchw_to_nhwc", x.data_ptr(), N, Cin, H, W, out.ptr, dt(dtype), C, out.ld, dev, st)
+    return out
+
+
+# ------------------------------------------------------------------------------------ convolution
+def conv_pack(w, dtype, seg0=0, want_fwd=True, want_bwd=True):
+    """fp32 [Cout,Cin,k,k] -> (forward image, data-gradient image) byte tensors."""
+    Cout, Cin, kh, kw = w.shape
+    taps = kh * kw
+    assert taps in (1, 9) and w.dtype == torch.float32 and w.is_contiguous()
+    nbytes = query("segk_conv_packed_bytes", dt(dtype), Cout, Cin, taps, seg0)
+    wf = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if want_fwd else None
+    wb = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if want_bwd else None
+    dev, st = _env(w)
+    call("segk_conv_pack", w.data_ptr(), Cout, Cin, taps, seg0, dt(dtype), _p(wf), _p(wb), dev, st)
+    return wf, wb
+
+
+def _segs(x):
+    if isinstance(x, Act):
+        return x, None
+    a, b = x
+    return a, b
+
+
+def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, accumulate=False):
+    """out = conv(x) with the packed image `w_packed`; x is an Act or a pair of Acts (channel concat)."""
+    a, b = _segs(x)
+    assert out.C == Cout and (out.N, out.H, out.W) == (a.N, a.H, a.W) and out.dtype == a.dtype
+    dev, st = _env(a.buf)
+    flags = (RELU if relu else 0) | (ACCUM if accumulate else 0)
+    call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
+         a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), out.ptr, out.ld, mask.ptr if mask else None,
+         mask.ld if mask else 0, flags, dev, st)
+    return out
+
+
+def conv_wgrad(x, dy, dw, taps=9, cin_real=None, accumulate=False):
+    """dw (fp32 [Cout, cin_real, taps]) = sum_pixels dy (x) shifted x."""
+    a, b = _segs(x)
+    Cout = dy.C
+    cin = a.C + (b.C if b else 0)
+    cin_real = cin_real or cin
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == Cout * cin_real * taps
+    dev, st = _env(a.buf)
+    d = dt(a.dtype)
+    nbytes = query("segk_conv_wgrad_workspace", d, taps, a.C, b.C if b else 0, a.N, a.H, a.W, Cout)
+    ws = workspace(nbytes, a.device)
+    call("segk_conv_wgrad", d, taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0, a.N, a.H,
+         a.W, dy.ptr, dy.ld, Cout, cin_real, dw.data_ptr(), ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
+    return dw
+
+
+def head_fwd(x, w, bias, logits):
+    Cout = w.shape[0]
+    dev, st = _env(x.buf)
+    call("segk_head1x1_fwd", dt(x.dtype), x.ptr, x.ld, x.C, x.N, x.H * x.W, w.data_ptr(), _p(bias), Cout, logits.data_ptr(),
+         dev, st)
+    return logits
+
+
+def head_bwd(x, w, dlogits, dx, relu_mask, dw, db):
+    Cout = w.shape[0]
+    dev, st = _env(x.buf)
+    nbytes = query("segk_head1x1_bwd_workspace", x.C, Cout, x.N, x.H * x.W)
+    ws = workspace(nbytes, x.device)
+    call("segk_head1x1_bwd", dt(x.dtype), x.ptr, x.ld, x.C, x.N, x.H * x.W, w.data_ptr(), Cout, dlogits.data_ptr(), dx.ptr,
+         dx.ld, 1 if relu_mask else 0, dw.data_ptr(), _p(db), ws.data_ptr(), ws.numel(), dev, st)
+
+
+# ------------------------------------------------------------------------------------ normalisation
+def norm_stats(x, groups, eps, stats, running_mean=None, running_var=None, momentum=0.1):
+    M = x.P // groups
+    dev, st = _env(x.buf)
+    ws = workspace(query("segk_norm_workspace", groups, M, x.C), x.device)
+    call("segk_norm_stats", dt(x.dtype), x.ptr, x.ld, groups, M, x.C, eps, stats.data_ptr(), _p(running_mean),
+         _p(running_var), momentum, ws.data_ptr(), ws.numel(), dev, st)
+    return stats
+
+
+def norm_eval_stats(running_mean, running_var, eps, stats):
+    dev, st = _env(running_mean)
+    call("segk_norm_eval_stats", running_mean.data_ptr(), running_var.data_ptr(), running_mean.numel(), eps,
+         stats.data_ptr(), dev, st)
+    return stats
+
+
+def norm_apply(x, groups, stats, gamma, beta, relu, out):
+    M = x.P // groups
+    dev, st = _env(x.buf)
+    call("segk_norm_apply", dt(x.dtype), x.ptr, x.ld, groups, M, x.C, stats.data_ptr(), _p(gamma), _p(beta),
+         RELU if relu else 0, out.ptr, out.ld, dev, st)
+    return out
+
+
+def norm_bwd(dy, x, groups, stats, gamma, beta, relu, dx, dgamma=None, dbeta=None, dbias=None, accumulate=False, frozen=False):
+    M = x.P // groups
+    dev, st = _env(x.buf)
+    ws = workspace(query("segk_norm_workspace", groups, M, x.C), x.device)
+    flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (FROZEN if frozen else 0)
+    call("segk_norm_bwd", dt(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, groups, M, x.C, stats.data_ptr(), _p(gamma), _p(beta),
+         flags, dx.ptr, dx.ld, _p(dgamma), _p(dbeta), _p(dbias), ws.data_ptr(), ws.numel(), dev, st)
+    return dx
+
+
+# ------------------------------------------------------------------------------------ resampling
+def maxpool_fwd(x, out):
+    dev, st = _env(x.buf)
+    call("segk_maxpool2x2_fwd", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, out.ptr, out.ld, dev, st)
+    return out
+
+
+def maxpool_bwd(x, dy, dx, accumulate=False):
+    dev, st = _env(x.buf)
+    call("segk_maxpool2x2_bwd", dt(x.dtype), x.ptr, x.ld, dy.ptr, dy.ld, x.N, x.H, x.W, x.C, dx.ptr, dx.ld,
+         ACCUM if accumulate else 0, dev, st)
+    return dx
+
+
+def upsample_fwd(x, out, stats=None, relu=False, align=False):
+    dev, st = _env(x.buf)
+    call("segk_upsample2x_fwd", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, _p(stats),
+         (RELU if relu else 0) | (ALIGN if align else 0), out.ptr, out.ld, dev, st)
+    return out
+
+
+def upsample_bwd(dy, y, dx, relu=False, align=False):
+    """dx has the low-resolution shape; y is the saved forward output (only read when relu)."""
+    dev, st = _env(dy.buf)
+    call("segk_upsample2x_bwd", dt(dy.dtype), dy.ptr, dy.ld, y.ptr if y is not None else None, y.ld if y is not None else 0,
+         dx.N, dx.H, dx.W, dx.C, (RELU if relu else 0) | (ALIGN if align else 0), dx.ptr, dx.ld, dev, st)
+    return dx
+
+
+def colsum(x, out, accumulate=False):
+    dev, st = _env(x.buf)
+    ws = workspace(query("segk_colsum_workspace", x.P, x.C), x.device)
+    call("segk_colsum", dt(x.dtype), x.ptr, x.ld, x.P, x.C, out.data_ptr(), ACCUM if accumulate else 0, ws.data_ptr(),
+         ws.numel(), dev, st)
+    return out
+
+
+def copy_slice(src, dst, accumulate=False):
+    assert src.C == dst.C and src.P == dst.P
+    dev, st = _env(src.buf)
+    call("segk_copy_slice", dt(src.dtype), src.ptr, src.ld, dst.ptr, dst.ld, src.P, src.C, ACCUM if accumulate else 0, dev, st)
+    return dst
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    dev, st = _env(param)
+    call("segk_adam_step", param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), lr,
+         beta1, beta2, eps, weight_decay, step, grad_scale, dev, st)

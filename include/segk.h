@@ -1,0 +1,237 @@
+/*
+ * segk -- C ABI of the MI355X (gfx950) segmentation-training-step kernels.
+ *
+ * The reference (PraiseThampiV/image-segmentation) is pure Python on stock PyTorch ops; it has no
+ * FFI.  Each entry point below therefore replaces the ATen call(s) issued by a reference line, which
+ * is cited per function (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative SEGK_E* code; segk_last_error() gives the
+ *     text of the last failure on the calling thread.
+ *   - pointers are DEVICE pointers unless the name ends in _host.  The caller (PyTorch) owns every
+ *     buffer; the library never allocates, frees, retains a pointer or synchronises.  Work is
+ *     enqueued on `stream` (a hipStream_t passed as void*) of device `dev`.
+ *   - activations are NHWC ("pixel-major"): element (n,y,x,c) of a tensor view lives at
+ *     ptr[((n*H + y)*W + x)*ld + c]; `ld` (elements) may exceed C so that a view can be a channel
+ *     slice of a wider concat buffer.  dtype is SEGK_F32 or SEGK_BF16 for activations and packed
+ *     weights; statistics, master weights, gradients of weights, biases and logits are fp32.
+ *   - ptr and ld*sizeof(elem) must be 16-byte aligned for activations; channel counts are multiples
+ *     of 8.
+ */
+#ifndef SEGK_H
+#define SEGK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { SEGK_F32 = 0, SEGK_BF16 = 1 } segk_dtype;
+
+enum {
+    SEGK_OK = 0,
+    SEGK_EINVAL = -1,     /* bad enum / null pointer / flag combination */
+    SEGK_ESHAPE = -2,     /* unsupported or inconsistent shape          */
+    SEGK_EALIGN = -3,     /* pointer or leading dimension misaligned    */
+    SEGK_EWORKSPACE = -4, /* workspace too small                        */
+    SEGK_EHIP = -5        /* a HIP runtime call failed                  */
+};
+
+const char* segk_last_error(void);
+int segk_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Losses.  logits are NCHW (the layout the networks return, models/unetvgg.py:105), fp32 or bf16;
+ * labels are int64 [N,H,W] (loss/dice.py:47-52 scatter one-hot; loss/focal.py:102-103) or, for Dice
+ * only, an explicit fp32 target `hot` [N,C,H,W] (loss/dice.py:53-54).
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Bytes of workspace needed by segk_dice_focal_fwd for this shape. */
+size_t segk_dice_focal_workspace(int64_t N, int64_t C, int64_t HW);
+
+/* Fused softmax + squared-Dice sums + focal sum.
+ * replaces: loss/dice.py:55-72 (Softmax2d, p*g, p*p, g*g sums) and loss/focal.py:134-136,64-75
+ *           (cross_entropy(reduction='none'), softmax, focal weight, product, reduce).
+ * out_sums  [N*C*4] fp32: per (n,c) {sum p*g, sum p*p, sum g*g, sum focal_c}            (written)
+ * out_flags [N]     int32: 1 if image n has any non-zero target (loss/dice.py:82)        (written)
+ * focal_map optional [N,C,H,W] fp32 elementwise focal values (reduction='none')          (written)
+ * flags bit0: logits already are probabilities (no_sft, Dice only)                                */
+int segk_dice_focal_fwd(const void* logits, int logits_dtype, const int64_t* labels, const float* hot,
+                        int64_t N, int64_t C, int64_t HW, float gamma, const float* alpha, int flags,
+                        float* out_sums, int32_t* out_flags, float* focal_map, void* workspace,
+                        size_t workspace_bytes, int dev, void* stream);
+
+/* Reduce the per-(n,c) sums to the two scalars the reference returns.
+ * replaces: loss/dice.py:72-87 (dice table, bg drop, fg-image average; loss = 1 - coeff at :23) and
+ *           loss/focal.py:24-29 (mean over N*C*H*W or sum).
+ * out_scalars[0] = dice coefficient (the loss is 1 - it, loss/dice.py:23), [1] = focal loss, [2] = 1/div (0 when no image is selected),
+ * [3] = focal scale (1/(N*C*HW) for mean, 1 for sum).   flags bit1: keep channel 0 (is_all_chann),
+ * bit2: focal reduction is 'sum'.                                                                  */
+int segk_dice_focal_finalize(const float* sums, const int32_t* img_flags, int64_t N, int64_t C, int64_t HW,
+                             int flags, float* out_scalars, int dev, void* stream);
+
+/* dlogits = gscale[0]*d(dice loss)/dlogits + gscale[1]*d(focal loss)/dlogits   (closed forms of the
+ * autograd graph of loss/dice.py:55-86 and loss/focal.py:64-75,134-136).  gscale is a DEVICE pointer
+ * to two floats (upstream gradients), so no host synchronisation is needed.
+ * dlogits has the dtype/layout of logits.                                                          */
+int segk_dice_focal_bwd(const void* logits, int logits_dtype, const int64_t* labels, const float* hot,
+                        int64_t N, int64_t C, int64_t HW, float gamma, const float* alpha, int flags,
+                        const float* sums, const int32_t* img_flags, const float* scalars, const float* gscale,
+                        void* dlogits, int dev, void* stream);
+
+/* argmax mask + hard-Dice counts.  replaces loss/dice.py:129-163 (softmax, argmax, one-hot, sums).
+ * mask [N,HW] uint8 (optional), counts [N*C*3] fp32 {sum phat*g, sum phat, sum g}, flags as above. */
+int segk_argmax_dice(const void* logits, int logits_dtype, const int64_t* labels, int64_t N, int64_t C,
+                     int64_t HW, uint8_t* mask, float* counts, int32_t* out_flags, int dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Layout conversion at the network boundary.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* NCHW fp32 image [N,Cin,H,W] -> NHWC activation with Cout >= Cin channels (extra channels zero).
+ * replaces: nothing in the reference (it stays NCHW); boundary of models/unetvgg.py:90.           */
+int segk_nchw_to_nhwc(const float* src, int64_t N, int64_t Cin, int64_t H, int64_t W, void* dst,
+                      int dst_dtype, int64_t Cout, int64_t ld, int dev, void* stream);
+
+/* 3x3 patch gather of a few-channel NCHW fp32 image: dst[n,y,x, (ky*3+kx)*Cin + c] = src[n,c,y+ky-1,
+ * x+kx-1] (zero outside), channels >= 9*Cin are zero.  Feeds the first VGG convolution
+ * (models/unetvgg.py:72, Conv2d(3,64,3,padding=1)) to the MFMA kernel as a 1x1 convolution.       */
+int segk_im2col3x3(const float* src, int64_t N, int64_t Cin, int64_t H, int64_t W, void* dst,
+                   int dst_dtype, int64_t Cout, int64_t ld, int dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolutions on the matrix cores.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Input channels per K-row of the MFMA convolution for a dtype (64 for bf16, 32 for fp32).  Input
+ * segments whose channel count is not a multiple of it are zero-filled up to the next K-row.      */
+int segk_conv_krow(int dtype);
+
+/* Pack fp32 OIHW weights [Cout,Cin,KH,KW] (KH=KW=3: taps=9, or 1x1: taps=1) into MFMA operand images:
+ *   wf : forward image, consumed by segk_conv_fwd for y = conv(x, w).  If the input is the
+ *        concatenation of two segments, seg0 = channels of the first one (0 = single segment): each
+ *        segment starts on a K-row boundary of the image.
+ *   wb : data-gradient image (taps flipped, in/out channels swapped), consumed by segk_conv_fwd
+ *        called on dy (Cout channels) to produce dx with Cin channels.          (either may be NULL)
+ * replaces: the weight operand of F.conv2d / its backward (models/unetvgg.py:28,34,38,72-76).
+ * segk_conv_packed_bytes: size that holds either image.                                           */
+size_t segk_conv_packed_bytes(int dtype, int64_t Cout, int64_t Cin, int taps, int64_t seg0);
+int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, int taps, int64_t seg0, int dtype, void* wf,
+                   void* wb, int dev, void* stream);
+
+/* y[n,y,x,co] = act( bias[co] + sum_{tap,ci} x[n,y+ky-1,x+kx-1,ci] * w[co,ci,ky,kx] ) * (mask>0)
+ * replaces: nn.Conv2d(k=3,padding=1) forward (models/unetvgg.py:28,34,38,72-76,87;
+ *           models/unetplusplus.py:11,13) and -- called with the `wb` image on dy -- the
+ *           data-gradient half of its backward; taps=1 gives a 1x1 convolution.
+ * The input is the channel concatenation of up to two segments (x0 then x1; torch.cat at
+ * models/unetvgg.py:99-103, models/unetplusplus.py:64-79); C0, C1 multiples of 8.
+ * flags bit0: ReLU epilogue; mask (optional, same dtype, ld_mask): output is zeroed where mask<=0
+ * (ReLU backward of the producer fused into the data gradient).
+ * flags bit1: accumulate into y (y += result) instead of overwriting.                             */
+int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
+                  int64_t C1, int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout,
+                  const float* bias, void* y, int64_t ldy, const void* mask, int64_t ld_mask, int flags,
+                  int dev, void* stream);
+
+/* dw[co,ci,ky,kx] (fp32 OIHW, [Cout, cin_real, taps]) = sum_{n,y,x} dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]
+ * replaces: the weight-gradient half of Conv2d's backward.  The pixels are split over workgroups
+ * whose partial slabs are summed in fixed order (deterministic).  flags bit1: dw += result.
+ * cin_real: number of input channels present in dw; C0+C1 unless a single segment carries trailing
+ * padding channels (the im2col image of the first convolution).                                   */
+size_t segk_conv_wgrad_workspace(int dtype, int taps, int64_t C0, int64_t C1, int64_t N, int64_t H, int64_t W,
+                                 int64_t Cout);
+int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
+                    int64_t C1, int64_t N, int64_t H, int64_t W, const void* dy, int64_t ldy, int64_t Cout,
+                    int64_t cin_real, float* dw, int flags, void* workspace, size_t workspace_bytes, int dev,
+                    void* stream);
+
+/* 1x1 head: logits[n,co,y,x] (NCHW fp32) = bias[co] + sum_ci x[n,y,x,ci]*w[co,ci].
+ * replaces: models/unetvgg.py:88,105 (final = Conv2d(32,C,1)); models/unetplusplus.py:58,81.      */
+int segk_head1x1_fwd(int dtype, const void* x, int64_t ld, int64_t Cin, int64_t N, int64_t HW, const float* w,
+                     const float* bias, int64_t Cout, float* logits, int dev, void* stream);
+/* backward of the head: dx (NHWC, optionally masked by relu_out>0), dw [Cout,Cin], db [Cout].     */
+size_t segk_head1x1_bwd_workspace(int64_t Cin, int64_t Cout, int64_t N, int64_t HW);
+int segk_head1x1_bwd(int dtype, const void* x, int64_t ld, int64_t Cin, int64_t N, int64_t HW, const float* w,
+                     int64_t Cout, const float* dlogits, void* dx, int64_t ld_dx, int relu_mask, float* dw,
+                     float* db, void* workspace, size_t workspace_bytes, int dev, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Normalisation / activation / resampling streams (HBM-bound).
+ * `groups` statistics groups of `M` pixels each: BatchNorm2d -> groups=1, M=N*H*W;
+ * InstanceNorm2d -> groups=N, M=H*W.   C/8 must be a power of two <= 256.
+ * ---------------------------------------------------------------------------------------------- */
+size_t segk_norm_workspace(int64_t groups, int64_t M, int64_t C);
+
+/* mean / rstd (biased variance, eps) per (group, channel); optionally the BatchNorm running-buffer
+ * update running = (1-momentum)*running + momentum*stat with the UNBIASED variance.
+ * replaces: statistics half of F.batch_norm(training=True) / F.instance_norm
+ *           (models/unetvgg.py:29,35,70-76; models/unetplusplus.py:12,14).
+ * stats [groups*C*2] fp32 {mean, rstd} interleaved per channel.                                    */
+int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t groups, int64_t M, int64_t C, float eps,
+                    float* stats, float* running_mean, float* running_var, float momentum, void* workspace,
+                    size_t workspace_bytes, int dev, void* stream);
+
+/* y = act( (x-mean)*rstd*gamma + beta ); gamma/beta may be NULL (InstanceNorm2d(affine=False)).
+ * flags bit0: ReLU.  `stats` as produced above, or built from running buffers for eval mode.
+ * replaces: normalise half of batch_norm / instance_norm + nn.ReLU(inplace=True).                  */
+int segk_norm_apply(int dtype, const void* x, int64_t ldx, int64_t groups, int64_t M, int64_t C,
+                    const float* stats, const float* gamma, const float* beta, int flags, void* y, int64_t ldy,
+                    int dev, void* stream);
+
+/* stats for eval mode: {running_mean, 1/sqrt(running_var+eps)} interleaved.                        */
+int segk_norm_eval_stats(const float* running_mean, const float* running_var, int64_t C, float eps,
+                         float* stats, int dev, void* stream);
+
+/* Backward of y = act(norm(x)):  g = dy * (y_pre>0 if ReLU);  dgamma = sum g*xhat, dbeta = sum g,
+ * dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)).  Two launches inside: reduce, then dx.
+ * dgamma/dbeta (fp32 [C], BatchNorm only) may be NULL; dx may alias dy.  flags bit0: ReLU,
+ * bit1: dgamma/dbeta += .   dbias_out (optional fp32 [C]): column sum of dx (bias gradient of the
+ * convolution in front of the norm).
+ * replaces: autograd backward of batch_norm / instance_norm + ReLU.                                */
+int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const void* x, int64_t ldx, int64_t groups,
+                  int64_t M, int64_t C, const float* stats, const float* gamma, const float* beta, int flags,
+                  void* dx, int64_t ld_dx, float* dgamma, float* dbeta, float* dbias_out, void* workspace,
+                  size_t workspace_bytes, int dev, void* stream);
+
+/* 2x2/stride-2 max pool (models/unetvgg.py:73-79 VGG pools; models/unetplusplus.py:35).           */
+int segk_maxpool2x2_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
+                        void* y, int64_t ldy, int dev, void* stream);
+/* dx (+)= route(dy) to the first maximum in scan order.  flags bit1: accumulate into dx.          */
+int segk_maxpool2x2_bwd(int dtype, const void* x, int64_t ldx, const void* dy, int64_t ld_dy, int64_t N,
+                        int64_t H, int64_t W, int64_t C, void* dx, int64_t ld_dx, int flags, int dev,
+                        void* stream);
+
+/* y[n, 2h x 2w, c] = act( (bilinear_x2(x) - mean)*rstd ), align_corners selectable; stats NULL means
+ * no normalisation.  replaces: InstanceNorm2d + nn.Upsample(scale_factor=2, mode='bilinear') + ReLU
+ * of the decoder block (models/unetvgg.py:35-36,41) and nn.Upsample(align_corners=True)
+ * (models/unetplusplus.py:36).   flags bit0: ReLU, bit2: align_corners=True.                       */
+int segk_upsample2x_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
+                        const float* stats, int flags, void* y, int64_t ldy, int dev, void* stream);
+/* adjoint: dxhat[n,h,w,c] = sum over the output pixels that read (h,w) of weight * dy * (y>0 if ReLU);
+ * y (the saved forward output) is only read when bit0 is set.                                      */
+int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, const void* y, int64_t ldy, int64_t N,
+                        int64_t H, int64_t W, int64_t C, int flags, void* dx, int64_t ld_dx, int dev,
+                        void* stream);
+
+/* out[c] = sum over pixels of x[p,c] (fp32, deterministic two-stage); flags bit1: out += .
+ * replaces: bias gradient of Conv2d/ConvTranspose2d backward.                                      */
+size_t segk_colsum_workspace(int64_t P, int64_t C);
+int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int64_t C, float* out, int flags,
+                void* workspace, size_t workspace_bytes, int dev, void* stream);
+
+/* dst[p, c] (+)= src[p, c] for a [P,C] channel slice (gradient fan-in of a tensor with several
+ * consumers, e.g. the dense skips of models/unetplusplus.py:64-79).  flags bit1: accumulate.       */
+int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t P,
+                    int64_t C, int flags, int dev, void* stream);
+
+/* Fused multi-tensor Adam step (torch.optim.Adam defaults; perlosstrain/naive_train.py:397-398,
+ * pl_utils/pl_mod.py:109-110).  One flat fp32 parameter / gradient / moment buffer.                */
+int segk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                   float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
+                   int dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGK_H */

@@ -1,0 +1,59 @@
+"""The C-ABI library loads and exports every symbol include/segk.h declares, with the ctypes prototypes the
+Python boundary uses (no compute calls: this runs without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    src = open(os.path.join(ROOT, "include", "segk.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return re.findall(r"(?:int|size_t|const char\*)\s+(segk_\w+)\s*\(([^)]*)\)\s*;", src)
+
+
+def test_header_matches_ctypes_prototypes():
+    from segk import _lib
+    kinds = {"int": _lib.I, "int64_t": _lib.L, "float": _lib.F, "size_t": _lib.Z}
+    decls = _header_decls()
+    assert len(decls) >= 30
+    for name, args in decls:
+        want = []
+        for a in args.split(","):
+            a = a.strip()
+            if a == "void":
+                continue
+            want.append(_lib.P if "*" in a else kinds[" ".join(a.split()[:-1])])
+        assert _lib._PROTOS[name][1] == want, name
+    assert set(_lib._PROTOS) == {n for n, _ in decls}
+
+
+def test_library_exports_every_declared_symbol():
+    from segk import _lib
+    if not _lib.available():
+        pytest.fail(f"{_lib.LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for name, _ in _header_decls():
+        assert hasattr(h, name), name
+    assert _lib.query("segk_version") >= 100
+    assert _lib.query("segk_conv_krow", _lib.SEGK_BF16) == 64 and _lib.query("segk_conv_krow", _lib.SEGK_F32) == 32
+    # pure host-side queries are safe without a GPU
+    assert _lib.query("segk_dice_focal_workspace", 32, 4, 384 * 384) > 0
+    assert _lib.query("segk_conv_wgrad_workspace", _lib.SEGK_BF16, 9, 64, 0, 32, 384, 384, 64) > 0
+    assert _lib.query("segk_conv_packed_bytes", _lib.SEGK_BF16, 64, 96, 9, 0) == 2 * 9 * 64 * 128
+
+
+def test_argument_validation_needs_no_gpu():
+    """Bad arguments are rejected on the host before any HIP call, with a readable message."""
+    from segk import _lib
+    with pytest.raises(_lib.SegkError, match="SEGK_EINVAL"):
+        _lib.call("segk_conv_pack", None, 64, 64, 9, 0, _lib.SEGK_BF16, None, None, 0, None)
+    with pytest.raises(_lib.SegkError, match="taps"):
+        _lib.call("segk_conv_pack", 16, 64, 64, 4, 0, _lib.SEGK_BF16, 16, None, 0, None)
+    with pytest.raises(_lib.SegkError, match="SEGK_ESHAPE"):
+        _lib.call("segk_maxpool2x2_fwd", _lib.SEGK_F32, 16, 8, 1, 3, 4, 8, 16, 8, 0, None)
+    with pytest.raises(_lib.SegkError, match="aligned"):
+        _lib.call("segk_norm_apply", _lib.SEGK_F32, 4, 8, 1, 16, 8, 16, None, None, 0, 16, 8, 0, None)

@@ -1,0 +1,164 @@
+"""Full-network parity on the GPU: logits / loss / parameter gradients / BatchNorm buffers / arg-max masks of
+the HIP path against the golden vectors captured from the reference (tests/golden/models.npz).
+
+fp32 path: rel <= 1e-4 (north-star bound) on logits and loss, masks bit-exact away from near-ties;
+bf16 path: rel <= 2e-2 (relative L2 per tensor), masks compared where the fp32 top-2 margin exceeds the
+bf16 logit error.
+"""
+import numpy as np
+import pytest
+import torch
+
+from util import rel_l2, report
+
+pytestmark = pytest.mark.gpu
+
+
+def build(name):
+    from models.unetvgg import UNetVgg, UNetVggInOut
+    if name == "unetvgg_c4":
+        return UNetVgg(out_classes=4), 3, 4
+    if name == "unetvgg_c3":
+        return UNetVgg(out_classes=3), 3, 3
+    if name == "unetvgg_c4_convtrans":
+        return UNetVgg(out_classes=4, if_convtrans=True), 3, 4
+    if name == "unetvgginout_c4":
+        return UNetVggInOut(in_classes=1, out_classes=4), 1, 4
+    if name == "nestedunet_c4":
+        from models.unetplusplus import Nested_UNet
+        return Nested_UNet(in_ch=1, out_ch=4), 1, 4
+    raise KeyError(name)
+
+
+def run_step(name, dtype, side=64, n=2, tag=None):
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from oracle.ref_models import hash_init_, synthetic_batch
+    from segk import _lib
+    model, in_ch, n_cls = build(name)
+    hash_init_(model)
+    model = model.cuda().train().set_compute_dtype(dtype)
+    x, t = synthetic_batch(n, side, n_cls, in_ch=in_ch, tag=tag or f"model:{name}")
+    before = _lib.launches
+    logits = model(x.cuda())
+    loss = dice_loss_sq(logits, t.cuda()) + focal_loss_with_logits(logits, t.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert _lib.launches - before > 50, "the HIP library did not run the network"
+    return model, logits.detach(), loss.detach()
+
+
+MODELS = ["unetvgg_c4", "unetvgg_c3", "unetvgginout_c4"]
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_fp32_step_vs_golden(name, golden):
+    g = golden["models"]
+    model, logits, loss = run_step(name, torch.float32)
+    want = torch.from_numpy(g[f"{name}/logits"])
+    report(f"{name}/logits", logits.cpu(), want, rtol=1e-4, atol=1e-4)
+    report(f"{name}/loss", loss.cpu(), torch.from_numpy(g[f"{name}/loss"]), rtol=1e-4, atol=1e-6)
+    # arg-max masks: bit-exact wherever the reference's top-2 margin exceeds the logit tolerance
+    top2 = want.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4e-4
+    mask = logits.argmax(1).to(torch.uint8).cpu()
+    assert torch.equal(mask[safe], torch.from_numpy(g[f"{name}/mask"])[safe])
+    assert int((~safe).sum()) <= 4 * int(g[f"{name}/near_tie_1e-3"]) + 8
+    worst = 0.0
+    for k, p in model.named_parameters():
+        assert p.grad is not None, k
+        gn = float(g[f"{name}/grad_norm/{k}"])
+        head = torch.from_numpy(g[f"{name}/grad_head/{k}"])
+        # gradients that are analytically zero (conv bias in front of a batch-statistics norm) are fp32 noise in the reference
+        if gn < 1e-6:
+            assert float(p.grad.norm()) < 1e-5, k
+            continue
+        err = abs(float(p.grad.double().norm()) - gn) / gn
+        worst = max(worst, err)
+        assert err < 1e-3, f"{k}: grad norm {float(p.grad.norm())} vs {gn}"
+        report(f"{name}/grad_head/{k}", p.grad.flatten()[:16].cpu(), head, rtol=2e-3, atol=2e-3 * gn / max(p.numel(), 1) ** 0.5 + 1e-7)
+    for k, b in model.named_buffers():
+        if k.endswith("num_batches_tracked"):
+            assert int(b) == 1
+        else:
+            report(f"{name}/buf/{k}", b.cpu(), torch.from_numpy(g[f"{name}/buf/{k}"]), rtol=1e-4, atol=1e-5)
+    # eval mode uses the running buffers just updated
+    model.eval()
+    from oracle.ref_models import synthetic_batch
+    in_ch = 1 if "inout" in name or "nested" in name else 3
+    x, _ = synthetic_batch(2, 64, 3 if name.endswith("c3") else 4, in_ch=in_ch, tag=f"model:{name}")
+    with torch.no_grad():
+        le = model(x.cuda())
+    report(f"{name}/eval_logits", le[..., ::4, ::4].cpu(), torch.from_numpy(g[f"{name}/eval_logits_sub"]), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", MODELS[:1])
+def test_bf16_step_vs_golden(name, golden):
+    g = golden["models"]
+    model, logits, loss = run_step(name, torch.bfloat16)
+    want = torch.from_numpy(g[f"{name}/logits"])
+    assert rel_l2(logits, want) < 2e-2, rel_l2(logits, want)
+    assert abs(float(loss) - float(g[f"{name}/loss"])) < 2e-2 * float(g[f"{name}/loss"])
+    err = float((logits.cpu() - want).abs().max())
+    top2 = want.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * err
+    assert torch.equal(logits.argmax(1).to(torch.uint8).cpu()[safe], torch.from_numpy(g[f"{name}/mask"])[safe])
+    assert float(safe.float().mean()) > 0.9
+    bad = []
+    for k, p in model.named_parameters():
+        gn = float(g[f"{name}/grad_norm/{k}"])
+        if gn < 1e-6:
+            continue
+        e = abs(float(p.grad.double().norm()) - gn) / gn
+        if e > 5e-2:
+            bad.append((k, e))
+    assert not bad, bad
+
+
+def test_unetvgg384_fp32_mask(golden):
+    """One full-size slice (N=1, 384x384): mask, sub-sampled logits, loss and gradient norms."""
+    g = golden["models"]
+    model, logits, loss = run_step("unetvgg_c4", torch.float32, side=384, n=1, tag="model:unetvgg384")
+    want = torch.from_numpy(g["unetvgg384/logits_sub"])
+    report("unetvgg384/logits_sub", logits[..., ::8, ::8].cpu(), want, rtol=1e-4, atol=1e-4)
+    report("unetvgg384/loss", loss.cpu(), torch.from_numpy(g["unetvgg384/loss"]), rtol=1e-4, atol=1e-6)
+    mask = logits.argmax(1).to(torch.uint8).cpu()
+    ref = torch.from_numpy(g["unetvgg384/mask"])
+    diff = int((mask != ref).sum())
+    assert diff <= int(g["unetvgg384/near_tie_1e-3"]), f"{diff} mask pixels differ"
+    for k, p in model.named_parameters():
+        gn = float(g[f"unetvgg384/grad_norm/{k}"])
+        if gn > 1e-6:
+            assert abs(float(p.grad.double().norm()) - gn) / gn < 1e-3, k
+
+
+def test_bench_shape_properties():
+    """BASELINE shape (batch 32, 384x384, bf16): size-independent properties instead of an oracle run."""
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetvgg import UNetVgg
+    from oracle.ref_models import hash_init_, synthetic_batch
+    model = hash_init_(UNetVgg(out_classes=4)).cuda().train().set_compute_dtype(torch.bfloat16)
+    x, t = synthetic_batch(8, 384, 4, tag="bench")
+    x, t = x.cuda(), t.cuda()
+    outs = []
+    for _ in range(2):
+        model.zero_grad()
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        logits = model(x)
+        loss = dice_loss_sq(logits, t) + focal_loss_with_logits(logits, t)
+        loss.backward()
+        outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    # deterministic: two runs give identical bits (fixed-order reductions everywhere)
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
+    assert torch.isfinite(outs[0][0]).all()
+    # batch independence of everything but BatchNorm statistics: in eval mode image i's logits do not depend on the others
+    model.eval()
+    with torch.no_grad():
+        full = model(x)
+        part = model(x[2:4])
+    assert torch.equal(full[2:4], part)

@@ -1,0 +1,268 @@
+"""GPU parity of every HIP kernel against the plain ATen op the reference calls (computed on the CPU in
+fp32/fp64 from the same, dtype-rounded inputs).  All calls go through the C ABI (segk.ops -> ctypes).
+
+Tolerances: fp32 path rel 1e-4 (the north-star bound; most kernels land at 1e-6), bf16 path rel 2e-2.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from util import report
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+TOL = {torch.float32: dict(rtol=1e-4, atol=1e-4), torch.bfloat16: dict(rtol=2e-2, atol=2e-2)}
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).float()   # values exactly representable in dtype
+
+
+def to_act(x, dtype, ld=None, c0=0):
+    """NCHW fp32 (CPU) -> Act on the GPU, optionally as a channel slice of a wider buffer."""
+    from segk.ops import Act
+    N, C, H, W = x.shape
+    ld = ld or C
+    buf = torch.full((N, H, W, ld), 7.0, dtype=dtype, device="cuda")
+    buf[..., c0:c0 + C] = x.permute(0, 2, 3, 1).to(dtype).cuda()
+    return Act(buf, c0, C)
+
+
+def from_act(a):
+    return a.nchw().float().cpu()
+
+
+# ---------------------------------------------------------------------------------------- convolution
+CONV_CASES = [
+    # N, H, W, Cin, Cout
+    (2, 16, 16, 64, 64),
+    (1, 24, 40, 128, 128),    # tiles not filling the image; BN=128 path
+    (2, 12, 12, 96, 32),      # partial K-row (bf16), BN=32 path, image smaller than a tile
+    (1, 32, 48, 32, 256),
+    (3, 8, 16, 192, 96),      # BN=32 with 3 channel blocks
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_fwd_dgrad_wgrad(dtype, case):
+    from segk import ops
+    N, H, W, Cin, Cout = case
+    x = rnd((N, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, 3, 3), dtype, 2, scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = rnd((Cout,), torch.float32, 3)
+    dy = rnd((N, Cout, H, W), dtype, 4)
+    xa = to_act(x, dtype, ld=Cin + 16, c0=8)
+    wf, wb = ops.conv_pack(w.cuda(), dtype)
+    # forward (+bias, +ReLU)
+    out = ops.Act.empty(N, H, W, Cout, dtype, "cuda")
+    ops.conv_fwd(xa, wf, Cout, out, bias=b.cuda(), relu=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    report("conv_fwd", from_act(out), ref, **TOL[dtype])
+    # data gradient (+mask, into a slice), then accumulate a second time
+    dya = to_act(dy, dtype)
+    mask = rnd((N, Cin, H, W), dtype, 5)
+    ma = to_act(mask, dtype)
+    dx = ops.Act(torch.zeros(N, H, W, Cin + 8, dtype=dtype, device="cuda"), 8, Cin)
+    ops.conv_fwd(dya, wb, Cin, dx, mask=ma)
+    ref_dx = F.conv_transpose2d(dy.double(), w.double(), padding=1).float() * (mask > 0)
+    report("conv_dgrad", from_act(dx), ref_dx, **TOL[dtype])
+    ops.conv_fwd(dya, wb, Cin, dx, mask=ma, accumulate=True)
+    t2 = dict(TOL[dtype]); t2["atol"] *= 2
+    report("conv_dgrad_accum", from_act(dx), 2 * ref_dx, **t2)
+    # weight gradient
+    dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
+    ops.conv_wgrad(xa, dya, dw)
+    ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1).float()
+    scale = float(ref_dw.abs().max())
+    report("conv_wgrad", dw.cpu(), ref_dw, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * max(scale, 1.0) * 0.05)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_conv_two_segments(dtype):
+    from segk import ops
+    N, H, W, C0, C1, Cout = 2, 16, 32, 96, 64, 64
+    x0, x1 = rnd((N, C0, H, W), dtype, 11), rnd((N, C1, H, W), dtype, 12)
+    w = rnd((Cout, C0 + C1, 3, 3), dtype, 13, scale=0.05)
+    dy = rnd((N, Cout, H, W), dtype, 14)
+    a0, a1 = to_act(x0, dtype), to_act(x1, dtype, ld=C1 + 32, c0=32)
+    wf, wb = ops.conv_pack(w.cuda(), dtype, seg0=C0)
+    out = ops.Act.empty(N, H, W, Cout, dtype, "cuda")
+    ops.conv_fwd((a0, a1), wf, Cout, out)
+    x = torch.cat([x0, x1], 1)
+    report("conv_fwd_2seg", from_act(out), F.conv2d(x.double(), w.double(), padding=1).float(), **TOL[dtype])
+    dya = to_act(dy, dtype)
+    dx = ops.Act.empty(N, H, W, C0 + C1, dtype, "cuda")
+    ops.conv_fwd(dya, wb, C0 + C1, dx)
+    report("conv_dgrad_2seg", from_act(dx), F.conv_transpose2d(dy.double(), w.double(), padding=1).float(), **TOL[dtype])
+    dw = torch.empty_like(w, device="cuda")
+    ops.conv_wgrad((a0, a1), dya, dw)
+    ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1).float()
+    report("conv_wgrad_2seg", dw.cpu(), ref_dw, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * float(ref_dw.abs().max()) * 0.05)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_first_conv_im2col(dtype):
+    from segk import ops
+    N, H, W, Cin, Cout = 2, 24, 32, 3, 64
+    x = rnd((N, Cin, H, W), torch.float32, 21)
+    w = rnd((Cout, Cin, 3, 3), dtype, 22, scale=0.2)
+    b = rnd((Cout,), torch.float32, 23)
+    dy = rnd((N, Cout, H, W), dtype, 24)
+    patches = ops.im2col3x3(x.cuda(), dtype)
+    w1 = w.permute(0, 2, 3, 1).reshape(Cout, 27, 1, 1).contiguous().cuda()
+    wf, _ = ops.conv_pack(w1, dtype, want_bwd=False)
+    out = ops.Act.empty(N, H, W, Cout, dtype, "cuda")
+    ops.conv_fwd(patches, wf, Cout, out, taps=1, bias=b.cuda())
+    xr = x.to(dtype).float()
+    report("first_conv", from_act(out), F.conv2d(xr.double(), w.double(), b.double(), padding=1).float(), **TOL[dtype])
+    dw = torch.empty(Cout, 27, device="cuda")
+    ops.conv_wgrad(patches, to_act(dy, dtype), dw, taps=1, cin_real=27)
+    ref = torch.nn.grad.conv2d_weight(xr.double(), w.shape, dy.double(), padding=1).float()
+    got = dw.view(Cout, 3, 3, Cin).permute(0, 3, 1, 2).cpu()
+    report("first_conv_wgrad", got, ref, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * float(ref.abs().max()) * 0.05)
+
+
+# ---------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(4, 64, 24, 24), (2, 256, 8, 16), (3, 32, 48, 48)], ids=str)
+def test_batchnorm_relu_fwd_bwd(dtype, shape):
+    from segk import ops
+    N, C, H, W = shape
+    x = rnd(shape, dtype, 31) * 1.5 + 0.3
+    gamma, beta = rnd((C,), torch.float32, 32) * 0.2 + 1.0, rnd((C,), torch.float32, 33) * 0.2
+    dy = rnd(shape, dtype, 34)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    xa = to_act(x, dtype, ld=C + 8, c0=8)
+    stats = torch.empty(2 * C, device="cuda")
+    rmg, rvg = rm.cuda(), rv.cuda()
+    ops.norm_stats(xa, 1, 1e-5, stats, rmg, rvg, 0.1)
+    out = ops.Act.empty(N, H, W, C, dtype, "cuda")
+    ops.norm_apply(xa, 1, stats, gamma.cuda(), beta.cuda(), True, out)
+    xd = x.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rmd, rvd = rm.double(), rv.double()
+    ref = F.relu(F.batch_norm(xd, rmd, rvd, gd, bd, True, 0.1, 1e-5))
+    report("bn_relu_fwd", from_act(out), ref.float(), **TOL[dtype])
+    report("running_mean", rmg.cpu(), rmd.float(), rtol=1e-4, atol=1e-5)
+    report("running_var", rvg.cpu(), rvd.float(), rtol=1e-4, atol=1e-5)
+    ref.backward(dy.double())
+    dx = ops.Act.empty(N, H, W, C, dtype, "cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.norm_bwd(to_act(dy, dtype), xa, 1, stats, gamma.cuda(), beta.cuda(), True, dx, dgamma=dg, dbeta=db)
+    # elements whose pre-activation is within rounding of zero may flip the ReLU mask in bf16: compare robustly
+    report("bn_relu_bwd_dx", from_act(dx), xd.grad.float(), **TOL[dtype])
+    n = N * H * W
+    report("bn_dgamma", dg.cpu(), gd.grad.float(), rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * n ** 0.5)
+    report("bn_dbeta", db.cpu(), bd.grad.float(), rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * n ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("align", [False, True], ids=["ac0", "ac1"])
+def test_instnorm_upsample_relu(dtype, align):
+    from segk import ops
+    N, C, H, W = 2, 64, 12, 20
+    x = rnd((N, C, H, W), dtype, 41) + 0.2
+    dy = rnd((N, C, 2 * H, 2 * W), dtype, 42)
+    xa = to_act(x, dtype)
+    stats = torch.empty(2 * N * C, device="cuda")
+    ops.norm_stats(xa, N, 1e-5, stats)
+    out = ops.Act(torch.zeros(N, 2 * H, 2 * W, C + 32, dtype=dtype, device="cuda"), 0, C)
+    ops.upsample_fwd(xa, out, stats=stats, relu=True, align=align)
+    xd = x.double().requires_grad_(True)
+    ref = F.relu(F.interpolate(F.instance_norm(xd, eps=1e-5), scale_factor=2, mode="bilinear", align_corners=align))
+    report("in_up_relu_fwd", from_act(out), ref.float(), **TOL[dtype])
+    ref.backward(dy.double())
+    dxh = ops.Act.empty(N, H, W, C, dtype, "cuda")
+    ops.upsample_bwd(to_act(dy, dtype), out, dxh, relu=True, align=align)
+    dx = ops.Act.empty(N, H, W, C, dtype, "cuda")
+    ops.norm_bwd(dxh, xa, N, stats, None, None, False, dx)
+    t = dict(TOL[dtype]); t["atol"] *= 4
+    report("in_up_relu_bwd", from_act(dx), xd.grad.float(), **t)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_upsample_plain(dtype):
+    from segk import ops
+    N, C, H, W = 1, 32, 6, 10
+    x, dy = rnd((N, C, H, W), dtype, 43), rnd((N, C, 2 * H, 2 * W), dtype, 44)
+    for align in (False, True):
+        out = ops.Act.empty(N, 2 * H, 2 * W, C, dtype, "cuda")
+        ops.upsample_fwd(to_act(x, dtype), out, align=align)
+        xd = x.double().requires_grad_(True)
+        ref = F.interpolate(xd, scale_factor=2, mode="bilinear", align_corners=align)
+        report(f"up_fwd_ac{align}", from_act(out), ref.float(), **TOL[dtype])
+        ref.backward(dy.double())
+        dx = ops.Act.empty(N, H, W, C, dtype, "cuda")
+        ops.upsample_bwd(to_act(dy, dtype), None, dx, align=align)
+        report(f"up_bwd_ac{align}", from_act(dx), xd.grad.float(), **TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_maxpool(dtype):
+    from segk import ops
+    N, C, H, W = 2, 64, 12, 16
+    x = rnd((N, C, H, W), dtype, 51)
+    x[:, :, ::4, ::4] = x[:, :, 1::4, 1::4]       # exact ties inside windows: first maximum must win
+    dy = rnd((N, C, H // 2, W // 2), dtype, 52)
+    xa = to_act(x, dtype, ld=C + 8)
+    out = ops.Act.empty(N, H // 2, W // 2, C, dtype, "cuda")
+    ops.maxpool_fwd(xa, out)
+    xd = x.double().requires_grad_(True)
+    ref = F.max_pool2d(xd, 2, 2)
+    report("pool_fwd", from_act(out), ref.float(), rtol=0, atol=0)
+    ref.backward(dy.double())
+    dx = ops.Act(torch.ones(N, H, W, C, dtype=dtype, device="cuda"))
+    ops.maxpool_bwd(xa, to_act(dy, dtype), dx, accumulate=True)
+    report("pool_bwd_accum", from_act(dx), xd.grad.float() + 1, rtol=1e-6 if dtype == torch.float32 else 1e-2, atol=1e-6 if dtype == torch.float32 else 1e-2)
+    ops.maxpool_bwd(xa, to_act(dy, dtype), dx)
+    report("pool_bwd", from_act(dx), xd.grad.float(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+def test_head_and_colsum(dtype):
+    from segk import ops
+    N, Cin, H, W, Cout = 2, 32, 16, 24, 4
+    x = F.relu(rnd((N, Cin, H, W), dtype, 61))
+    w, b = rnd((Cout, Cin), torch.float32, 62, 0.3), rnd((Cout,), torch.float32, 63)
+    dl = rnd((N, Cout, H, W), torch.float32, 64)
+    xa = to_act(x, dtype)
+    logits = torch.empty(N, Cout, H, W, device="cuda")
+    ops.head_fwd(xa, w.cuda(), b.cuda(), logits)
+    xd = x.double().requires_grad_(True)
+    wd, bd = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = F.conv2d(xd, wd[:, :, None, None], bd)
+    report("head_fwd", logits.cpu(), ref.float(), rtol=1e-5, atol=1e-5)
+    ref.backward(dl.double())
+    dx = ops.Act.empty(N, H, W, Cin, dtype, "cuda")
+    dw, db = torch.empty(Cout, Cin, device="cuda"), torch.empty(Cout, device="cuda")
+    ops.head_bwd(xa, w.cuda(), dl.cuda(), dx, True, dw, db)
+    report("head_dx", from_act(dx), (xd.grad * (x > 0)).float(), **TOL[dtype])
+    report("head_dw", dw.cpu(), wd.grad.float(), rtol=1e-4, atol=1e-3)
+    report("head_db", db.cpu(), bd.grad.float(), rtol=1e-4, atol=1e-3)
+    s = torch.empty(Cin, device="cuda")
+    ops.colsum(xa, s)
+    report("colsum", s.cpu(), x.double().sum((0, 2, 3)).float(), rtol=1e-5, atol=1e-3)
+    ops.colsum(xa, s, accumulate=True)
+    report("colsum_accum", s.cpu(), 2 * x.double().sum((0, 2, 3)).float(), rtol=1e-5, atol=2e-3)
+
+
+def test_copy_slice_and_adam():
+    from segk import ops
+    a = rnd((2, 40, 6, 6), torch.float32, 71)
+    src = to_act(a, torch.float32)
+    dst = ops.Act(torch.ones(2, 6, 6, 64, device="cuda"), 16, 40)
+    ops.copy_slice(src, dst, accumulate=True)
+    report("copy_accum", from_act(dst), a + 1, rtol=1e-6, atol=1e-6)
+    assert float(dst.buf[..., :16].sub(1).abs().max()) == 0 and float(dst.buf[..., 56:].sub(1).abs().max()) == 0
+    p0, g = rnd((1000,), torch.float32, 72), rnd((1000,), torch.float32, 73)
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p_ref], lr=1e-2)
+    p, m, v = p0.cuda(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for step in (1, 2, 3):
+        p_ref.grad = g * step
+        opt.step()
+        ops.adam_step(p, (g * step).cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.0, step)
+    report("adam", p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)

@@ -1,0 +1,159 @@
+"""CPU tests: the oracle restatement reproduces the golden vectors captured from the reference, and the
+product's host-side surface (module tree, state_dict layout, CPU-tensor path, error behaviour) mirrors it."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from util import report
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_oracle_pin_recorded():
+    pin = json.load(open(os.path.join(ROOT, "tests", "golden", "oracle_pin.json")))
+    assert pin["all_bitwise_equal"] and all(pin["checks"].values())
+    assert len(pin["checks"]) >= 40
+
+
+def test_oracle_losses_match_golden(golden):
+    from oracle import ref_losses as RL
+    from oracle.cases import loss_cases, make_loss_inputs
+    g = golden["losses"]
+    for name, C, N, side, kw in loss_cases():
+        if side > 64:
+            continue
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        dkw = {k: kw[k] for k in ("no_sft", "is_all_chann") if k in kw}
+        fkw = {k: kw[k] for k in ("gamma", "reduction") if k in kw}
+        if "alpha" in kw:
+            fkw["alpha"] = torch.tensor(kw["alpha"])
+        zin = torch.softmax(z, 1) if kw.get("no_sft") else z
+        a = zin.clone().requires_grad_(True)
+        ld = RL.dice_loss_sq(a, t, **dkw)
+        ld.backward()
+        assert np.array_equal(ld.detach().numpy(), g[f"{name}/dice"])
+        assert np.array_equal(a.grad.numpy(), g[f"{name}/dice_grad"])
+        b = z.clone().requires_grad_(True)
+        lf = RL.focal_loss_with_logits(b, t, **fkw)
+        lf.backward()
+        assert np.array_equal(lf.detach().numpy(), g[f"{name}/focal"])
+        assert np.array_equal(b.grad.numpy(), g[f"{name}/focal_grad"])
+        assert np.array_equal(RL.dice_coefficient(z, t).numpy(), g[f"{name}/metric"])
+        # closed forms used by the HIP backward agree with autograd (double precision)
+        if not dkw and not fkw:
+            cf = RL.dice_focal_closed_form_grad(z, t)
+            report(f"{name}/closed_form", cf.float(), a.grad + b.grad, rtol=1e-4, atol=1e-7)
+
+
+def test_oracle_known_answers(golden):
+    from oracle import ref_losses as RL
+    z = torch.zeros(2, 4, 8, 8)
+    t = torch.zeros(2, 8, 8, dtype=torch.long)
+    t[:, :4, :] = 1
+    t[0, 4:, :4] = 2
+    assert abs(float(RL.focal_loss_with_logits(z, t)) - 0.75 / 4 * np.log(4)) < 1e-7
+    assert abs(float(RL.dice_loss_sq(z, t)) - 0.67541826) < 1e-7
+    assert float(RL.dice_loss_sq(z, torch.zeros_like(t))) == 1.0
+    assert float(RL.dice_coefficient(z, torch.zeros_like(t))) == 0.0
+    with pytest.raises(RuntimeError):
+        RL.dice_loss_sq(torch.zeros(1, 4, 8, 12), torch.zeros(1, 8, 12, dtype=torch.long))
+    with pytest.raises(ValueError, match="Reduction parameter unknown"):
+        RL.focal_loss_with_logits(z, t, reduction="bogus")
+    with pytest.raises(TypeError):
+        RL.dice_coefficient(z, torch.zeros(2, 4, 8, 8))
+
+
+def _product(name):
+    from models.unetvgg import UNetVgg, UNetVggInOut
+    from models.unetplusplus import Nested_UNet
+    return {
+        "unetvgg_c4": lambda: UNetVgg(out_classes=4),
+        "unetvgg_c3": lambda: UNetVgg(out_classes=3),
+        "unetvgg_c4_convtrans": lambda: UNetVgg(out_classes=4, if_convtrans=True),
+        "unetvgginout_c4": lambda: UNetVggInOut(in_classes=1, out_classes=4),
+        "nestedunet_c4": lambda: Nested_UNet(in_ch=1, out_ch=4),
+    }[name]()
+
+
+def _oracle(name):
+    from oracle import ref_models as RM
+    return {
+        "unetvgg_c4": lambda: RM.RefUNetVgg(out_classes=4),
+        "unetvgg_c3": lambda: RM.RefUNetVgg(out_classes=3),
+        "unetvgg_c4_convtrans": lambda: RM.RefUNetVgg(out_classes=4, if_convtrans=True),
+        "unetvgginout_c4": lambda: RM.RefUNetVgg(out_classes=4, in_classes=1),
+        "nestedunet_c4": lambda: RM.RefNestedUNet(in_ch=1, out_ch=4),
+    }[name]()
+
+
+ALL = ["unetvgg_c4", "unetvgg_c3", "unetvgg_c4_convtrans", "unetvgginout_c4", "nestedunet_c4"]
+
+
+@pytest.mark.parametrize("name", ALL)
+def test_state_dict_layout_matches_reference(name):
+    keys = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))[name]
+    sd = _product(name).state_dict()
+    assert list(sd.keys()) == list(keys.keys())
+    for k, v in sd.items():
+        assert list(v.shape) == keys[k], k
+    # a reference-layout checkpoint loads strictly
+    _product(name).load_state_dict(_oracle(name).state_dict(), strict=True)
+
+
+@pytest.mark.parametrize("name", ["unetvgg_c4", "nestedunet_c4"])
+def test_oracle_and_host_path_match_golden(name, golden):
+    """One train step on CPU: the oracle equals the golden vectors bit for bit, and the product's CPU-tensor
+    path (plain torch.nn modules holding the same parameters) equals the oracle."""
+    from oracle import ref_losses as RL
+    from oracle.ref_models import hash_init_, synthetic_batch
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    g = golden["models"]
+    in_ch = 1 if "nested" in name else 3
+    x, t = synthetic_batch(2, 64, 4, in_ch=in_ch, tag=f"model:{name}")
+    torch.set_num_threads(8)
+    m = hash_init_(_oracle(name)).train()
+    logits = m(x)
+    loss = RL.dice_loss_sq(logits, t) + RL.focal_loss_with_logits(logits, t)
+    loss.backward()
+    assert np.array_equal(logits.detach().numpy(), g[f"{name}/logits"])
+    assert np.array_equal(loss.detach().numpy(), g[f"{name}/loss"])
+    assert np.array_equal(logits.argmax(1).to(torch.uint8).numpy(), g[f"{name}/mask"])
+    p = hash_init_(_product(name)).train()
+    lp = p(x)
+    lossp = dice_loss_sq(lp, t) + focal_loss_with_logits(lp, t)
+    lossp.backward()
+    report("host logits", lp, logits, rtol=1e-5, atol=1e-5)
+    report("host loss", lossp, loss, rtol=1e-5, atol=1e-6)
+    for (k, a), (_, b) in zip(p.named_parameters(), m.named_parameters()):
+        report(k, a.grad, b.grad, rtol=1e-3, atol=1e-5)
+
+
+def test_constructor_surface():
+    from models.unetvgg import UNetVgg, UNetVggInOut, make_decoder_block
+    from models.unetplusplus import Nested_UNet, conv_block_nested
+    m = UNetVgg()
+    assert m.final.out_channels == 3 and m.patch_train is False
+    assert UNetVgg(out_classes=4, patch_train=True).patch_train is True
+    assert UNetVggInOut(in_classes=2).conv0.in_channels == 2
+    assert Nested_UNet().final.out_channels == 3
+    blk = make_decoder_block(8, 16, 4)
+    assert [type(c).__name__ for c in blk] == ["Conv2d", "ReLU", "Conv2d", "InstanceNorm2d", "Upsample", "ReLU"]
+    assert [type(c).__name__ for c in make_decoder_block(8, 16, 4, if_convtrans=True)] == ["Conv2d", "ReLU", "ConvTranspose2d", "ReLU"]
+    assert [type(c).__name__ for c in make_decoder_block(8, 16, 4, noupsam=True)] == ["Conv2d", "ReLU", "Conv2d", "InstanceNorm2d", "ReLU"]
+    assert blk(torch.zeros(1, 8, 4, 4)).shape == (1, 4, 8, 8)
+    assert conv_block_nested(3, 8, 8)(torch.zeros(2, 3, 4, 4)).shape == (2, 8, 4, 4)
+    with pytest.raises(RuntimeError, match="pretrained"):
+        UNetVgg(pretrained=True)
+
+
+def test_gpu_tensors_never_fall_back(monkeypatch):
+    """Without the HIP library a CUDA forward must raise rather than compute elsewhere."""
+    from segk import _lib
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libsegk.so")
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(_lib.SegkError, match="missing"):
+        _lib.lib()
