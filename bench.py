@@ -1,0 +1,179 @@
+"""Throughput of the segmentation training step on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): UNet-VGG (VGG16-BN encoder, bilinear decoder, 4 classes) on synthetic
+384x384 slices, 32 slices per GPU, bf16 kernels with fp32 accumulation/statistics, squared-Dice + focal loss.
+One step = forward + fused loss + backward (+ bucketed RCCL gradient all-reduce when N > 1) + fused Adam.
+Prints ONE JSON line on rank 0: whole-job slices/s, the MFMA roofline of the convolution kernels (HIP-event
+timed on the launch stream during the timed steps) and a CPU baseline of the oracle on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "image-segmentation_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+GFLOP_PER_SLICE = 509.72       # conv fwd+dgrad+wgrad of UNetVgg(out_classes=4) at 384x384, 2 FLOP/MAC, no dgrad on conv1.0
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MI355X matrix peaks
+
+
+def synthetic(batch, side, n_classes, device, seed=20):
+    """z-scored grey slice replicated to 3 channels; label map with a few small ellipses, 1 in 8 slices empty."""
+    g = torch.Generator().manual_seed(seed)
+    grey = torch.randn(batch, 1, side, side, generator=g)
+    x = grey.expand(batch, 3, side, side).contiguous()
+    yy, xx = torch.meshgrid(torch.arange(side), torch.arange(side), indexing="ij")
+    t = torch.zeros(batch, side, side, dtype=torch.int64)
+    for b in range(batch):
+        if b % 8 == 7:
+            continue
+        for c in range(1, n_classes):
+            cy, cx = side * (0.4 + 0.07 * c), side * (0.35 + 0.1 * c)
+            ry, rx = side * (0.04 + 0.01 * (b % 3)), side * 0.07
+            t[b][((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0] = c
+    return x.to(device), t.to(device)
+
+
+def cpu_baseline(n_classes, seconds_budget=25.0):
+    """The CPU oracle (plain torch.nn restatement pinned to the reference) on configs[0]: N=4, fp32, fwd+loss+bwd."""
+    from oracle import ref_losses as RL
+    from oracle.ref_models import RefUNetVgg
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    torch.manual_seed(20)
+    model = RefUNetVgg(out_classes=n_classes).train()
+    x, t = synthetic(4, 384, n_classes, "cpu")
+    times = []
+    t_start = time.perf_counter()
+    for i in range(4):
+        t0 = time.perf_counter()
+        model.zero_grad()
+        logits = model(x)
+        loss = RL.dice_loss_sq(logits, t) + RL.focal_loss_with_logits(logits, t)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > seconds_budget and i >= 1:
+            break
+    steady = times[1:] if len(times) > 1 else times
+    best = sorted(steady)[len(steady) // 2]
+    return {"value": round(4 / best, 4), "unit": "slices/s", "cores": threads, "kind": "port",
+            "sample": f"oracle RefUNetVgg fp32, batch 4 x 3x384x384, fwd+loss+bwd, median of {len(steady)} steps after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="slices per GPU")
+    ap.add_argument("--side", type=int, default=384)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetvgg import UNetVgg
+    from segk import ops
+    from segk.flat import FlatModel
+    from segk.optim import Adam
+
+    n_classes = 4
+    torch.manual_seed(20)
+    if args.model == "unetpp":
+        from models.unetplusplus import Nested_UNet
+        model = Nested_UNet(in_ch=1, out_ch=n_classes)
+        gflop = 1859.61
+    else:
+        model = UNetVgg(out_classes=n_classes, if_convtrans=args.model == "unetvgg_convtrans")
+        gflop = GFLOP_PER_SLICE if args.model == "unetvgg" else 539.05
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = model.to(device).train().set_compute_dtype(dtype)
+    flat = FlatModel(model)                    # flat params/grads; bucketed all-reduce when world > 1
+    opt = Adam(flat, lr=1e-4)
+    x, t = synthetic(args.batch, args.side, n_classes, device, seed=20 + rank)
+    if args.model == "unetpp":
+        x = x[:, :1].contiguous()
+
+    def step():
+        logits = model(x)
+        loss = dice_loss_sq(logits, t) + focal_loss_with_logits(logits, t)
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timer = None if args.no_roofline else []
+    ops.CONV_TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.CONV_TIMER = None
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt)
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        value = world * args.batch * args.steps / elapsed
+        out = {
+            "metric": "train slices/sec (fwd+bwd+loss) UNet-VGG 384x384", "value": round(value, 2), "unit": "slices/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.side}x{args.side}, {n_classes} classes, {args.batch} slices/GPU, "
+                                   f"fwd + fused Dice/focal loss + bwd + {'bucketed RCCL all-reduce + ' if world > 1 else ''}fused Adam",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "random_init_weights": True,
+                       "final_loss": round(final_loss, 5)},
+        }
+        if timer:
+            fwd = sum(a.elapsed_time(b) for k, a, b in timer if k == "conv_fwd")
+            wg = sum(a.elapsed_time(b) for k, a, b in timer if k == "conv_wgrad")
+            conv_ms = (fwd + wg) / args.steps
+            achieved = gflop * args.batch / conv_ms        # GFLOP / ms = TFLOP/s
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
+                               "frac": round(achieved / peak, 4), "traffic": None,
+                               "kernel": "conv_fwd_kernel + conv_wgrad_kernel (all MFMA convolution launches of a step)",
+                               "launches_per_step": len(timer) // args.steps, "conv_ms_per_step": round(conv_ms, 3),
+                               "fwd_dgrad_ms": round(fwd / args.steps, 3), "wgrad_ms": round(wg / args.steps, 3),
+                               "whole_step_mfma_frac": round(gflop * args.batch / ms / peak, 4)}
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n_classes)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -30,11 +30,11 @@ class _TapeFn(torch.autograd.Function):
     def forward(ctx, net, x, need_grad, *params):
         names = net._segk_param_names
         dtype = net.compute_dtype()
-        hooks = getattr(net, "_segk_grad_hooks", None) or (None, None)
+        hooks = getattr(net, "_segk_grad_hooks", None) or (None, None, None, None)
         rt = Runtime(dict(zip(names, params)), dict(net.named_buffers()), dtype, x.device, net.training, need_grad,
                      grad_sink=hooks[0], grad_alloc=hooks[1])
         logits = net._emit(rt, x)
-        ctx.rt, ctx.names = rt, names
+        ctx.rt, ctx.names, ctx.hooks = rt, names, hooks
         ctx.set_materialize_grads(False)
         return logits
 
@@ -43,10 +43,17 @@ class _TapeFn(torch.autograd.Function):
         rt = ctx.rt
         if dlogits is None:
             return (None, None, None) + tuple(None for _ in ctx.names)
+        begin, finish = ctx.hooks[2], ctx.hooks[3]
+        if begin is not None:
+            begin()
         rt.head_backward(dlogits)
         rt.backward()
-        grads = tuple(rt.grads.get(n) if ctx.needs_input_grad[3 + i] else None for i, n in enumerate(ctx.names))
         ctx.rt = None
+        if finish is not None:
+            # flat mode: gradients were written (and all-reduced) in place in the flat buffer that p.grad views
+            finish()
+            return (None, None, None) + tuple(None for _ in ctx.names)
+        grads = tuple(rt.grads.get(n) if ctx.needs_input_grad[3 + i] else None for i, n in enumerate(ctx.names))
         return (None, None, None) + grads
 
 

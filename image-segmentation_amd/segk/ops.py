@@ -71,6 +71,26 @@ def _env(t):
 
 _workspaces = {}
 
+# Optional per-launch timing of the MFMA convolutions (bench.py's roofline leg): a list that receives
+# (kind, start_event, end_event) for every conv launch, recorded on the stream the kernel runs on.
+CONV_TIMER = None
+
+
+class _Timed:
+    def __init__(self, kind):
+        self.kind = kind
+
+    def __enter__(self):
+        if CONV_TIMER is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *exc):
+        if CONV_TIMER is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            CONV_TIMER.append((self.kind, self.e0, e1))
+
 
 def workspace(nbytes, device):
     """Per-device scratch buffer; every kernel that uses it runs on the current stream, so successive
@@ -137,9 +157,10 @@ def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, a
     assert out.C == Cout and (out.N, out.H, out.W) == (a.N, a.H, a.W) and out.dtype == a.dtype
     dev, st = _env(a.buf)
     flags = (RELU if relu else 0) | (ACCUM if accumulate else 0)
-    call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
-         a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), out.ptr, out.ld, mask.ptr if mask else None,
-         mask.ld if mask else 0, flags, dev, st)
+    with _Timed("conv_fwd"):
+        call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
+             a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), out.ptr, out.ld, mask.ptr if mask else None,
+             mask.ld if mask else 0, flags, dev, st)
     return out
 
 
@@ -154,8 +175,9 @@ def conv_wgrad(x, dy, dw, taps=9, cin_real=None, accumulate=False):
     d = dt(a.dtype)
     nbytes = query("segk_conv_wgrad_workspace", d, taps, a.C, b.C if b else 0, a.N, a.H, a.W, Cout)
     ws = workspace(nbytes, a.device)
-    call("segk_conv_wgrad", d, taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0, a.N, a.H,
-         a.W, dy.ptr, dy.ld, Cout, cin_real, dw.data_ptr(), ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
+    with _Timed("conv_wgrad"):
+        call("segk_conv_wgrad", d, taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0, a.N, a.H,
+             a.W, dy.ptr, dy.ld, Cout, cin_real, dw.data_ptr(), ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
     return dw
 
 

@@ -131,7 +131,7 @@ def test_first_conv_im2col(dtype):
 def test_batchnorm_relu_fwd_bwd(dtype, shape):
     from segk import ops
     N, C, H, W = shape
-    x = rnd(shape, dtype, 31) * 1.5 + 0.3
+    x = (rnd(shape, dtype, 31) * 1.5 + 0.3).to(dtype).float()
     gamma, beta = rnd((C,), torch.float32, 32) * 0.2 + 1.0, rnd((C,), torch.float32, 33) * 0.2
     dy = rnd(shape, dtype, 34)
     rm, rv = torch.zeros(C), torch.ones(C)
@@ -164,7 +164,7 @@ def test_batchnorm_relu_fwd_bwd(dtype, shape):
 def test_instnorm_upsample_relu(dtype, align):
     from segk import ops
     N, C, H, W = 2, 64, 12, 20
-    x = rnd((N, C, H, W), dtype, 41) + 0.2
+    x = (rnd((N, C, H, W), dtype, 41) + 0.2).to(dtype).float()
     dy = rnd((N, C, 2 * H, 2 * W), dtype, 42)
     xa = to_act(x, dtype)
     stats = torch.empty(2 * N * C, device="cuda")
