@@ -62,23 +62,37 @@ template <> struct Mma<float> {
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
+// 16 zero bytes that padding lanes of an LDS-DMA load read instead of branching around the load
+__device__ const uint4 kZeroSlot = {0u, 0u, 0u, 0u};
+
+// One LDS-DMA transfer: every active lane moves 16 bytes from its own global address to
+// lds_wave_base + 16*lane (the destination is wave-uniform by construction of the hardware).
+__device__ __forceinline__ void glds16(const char* src, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
 template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES>
 __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a) {
     constexpr int PAD = TAPS == 9 ? 1 : 0;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_;
     constexpr int HSLOTS = HPIX * 8;
-    constexpr int HL = (HSLOTS + TAPS * kConvThreads - 1) / (TAPS * kConvThreads);   // halo loads / thread / step
-    constexpr int WL = BN * 8 / kConvThreads;                                        // weight loads / thread / step
+    constexpr int HL = (HSLOTS + TAPS * kConvThreads - 1) / (TAPS * kConvThreads);   // halo transfers / thread / step
+    constexpr int WL = BN * 8 / kConvThreads;                                        // weight transfers / thread / step
     static_assert(BN * 8 % kConvThreads == 0, "weight tile must split evenly");
     constexpr int WCO = BN / WCO_WAVES, WPX = TH * kTW / WPX_WAVES;
     constexpr int NI = WCO / 16, NJ = WPX / 16;
     static_assert(WPX_WAVES * WCO_WAVES == 4 && NI >= 1 && NJ >= 1, "bad wave layout");
     constexpr int EPS = 16 / (int)sizeof(T);   // elements per 16-byte slot
+    constexpr int HBYTES = HPIX * kRowBytes, WBYTES = BN * kRowBytes;
 
-    __shared__ __attribute__((aligned(16))) char s_halo[2][HPIX * kRowBytes];
-    __shared__ __attribute__((aligned(16))) char s_w[2][BN * kRowBytes];
+    // one LDS object: [halo 0 | halo 1 | weights 0 | weights 1]
+    __shared__ __attribute__((aligned(16))) char smem[2 * HBYTES + 2 * WBYTES];
+    char* const s_halo0 = smem;
+    char* const s_w0 = smem + 2 * HBYTES;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     const int wpx = wave % WPX_WAVES, wco = wave / WPX_WAVES;
 
@@ -92,41 +106,46 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
     const int n = sp / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * kTW;
 
-    // ---- staging helpers ---------------------------------------------------------------------
-    auto halo_src = [&](int chunk, int slot_id, bool& ok) -> const char* {
-        const int pix = slot_id >> 3, sl = slot_id & 7;
+    // ---- staging: global -> LDS by DMA (no registers, stays in flight behind the MFMAs) -------------
+    // LDS slot q of the halo image holds pixel q>>3, and -- because the DMA destination is linear in the
+    // lane index -- the swizzle is applied to the SOURCE: slot q receives channel slot (q&7) ^ (pixel&7).
+    // Padding (outside the image, past the segment's channels) reads the 16 zero bytes of kZeroSlot.
+    auto halo_src = [&](int chunk, int q) -> const char* {
+        const int pix = q >> 3, sl = (q & 7) ^ (pix & 7);
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
         const bool s0 = chunk < a.nch0;
         const char* base = s0 ? a.x0 : a.x1;
         const int64_t ld = s0 ? a.ld0 : a.ld1;
         const int ch = (s0 ? chunk : chunk - a.nch0) * KRow<T>::kElems + sl * EPS;
-        ok = slot_id < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < (s0 ? a.C0 : a.C1);
-        return base + ((((int64_t)n * a.H + gy) * a.W + gx) * ld + ch) * (int64_t)sizeof(T);
+        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < (s0 ? a.C0 : a.C1);
+        const int64_t off = ((((int64_t)n * a.H + gy) * a.W + gx) * ld + ch) * (int64_t)sizeof(T);
+        return ok ? base + off : reinterpret_cast<const char*>(&kZeroSlot);
     };
-    auto halo_dst = [&](int buf, int slot_id) -> char* {
-        const int pix = slot_id >> 3, sl = slot_id & 7;
-        return &s_halo[buf][pix * kRowBytes + ((sl ^ (pix & 7)) << 4)];
+    auto stage_halo_part = [&](int chunk, int buf, int part) {
+#pragma unroll
+        for (int k = 0; k < HL; ++k) {
+            const int qw = (part * HL + k) * kConvThreads + wave * 64;   // first slot of this wave's transfer
+            const int q = qw + lane;
+            if (q < HSLOTS) glds16(halo_src(chunk, q), s_halo0 + buf * HBYTES + qw * 16);
+        }
     };
-    auto w_src = [&](int step, int q) -> const char* {
-        return a.w + (((int64_t)step * a.cout_pad + (int64_t)cb * BN) * kRowBytes) + (int64_t)q * 16;
+    auto stage_w = [&](int step, int buf) {
+        const char* src = a.w + (((int64_t)step * a.cout_pad + (int64_t)cb * BN) * kRowBytes);
+#pragma unroll
+        for (int k = 0; k < WL; ++k) {
+            const int qw = k * kConvThreads + wave * 64;
+            glds16(src + (int64_t)(qw + lane) * 16, s_w0 + buf * WBYTES + qw * 16);
+        }
     };
 
-    Slot hreg[HL], wreg[WL];
     const int nsteps = a.nch * TAPS;
 
-    // ---- prologue: whole halo of chunk 0 and the weights of step 0 ---------------------------------
-    for (int s = tid; s < HSLOTS; s += kConvThreads) {
-        bool ok;
-        const char* src = halo_src(0, s, ok);
-        *reinterpret_cast<Slot*>(halo_dst(0, s)) = ok ? *reinterpret_cast<const Slot*>(src) : zero_slot();
-    }
+    // ---- prologue: whole halo of K-row 0 and the weights of step 0 -----------------------------------
 #pragma unroll
-    for (int k = 0; k < WL; ++k) {
-        const int q = tid + k * kConvThreads;
-        *reinterpret_cast<Slot*>(&s_w[0][q * 16]) = *reinterpret_cast<const Slot*>(w_src(0, q));
-    }
-    __syncthreads();
+    for (int part = 0; part < TAPS; ++part) stage_halo_part(0, 0, part);
+    stage_w(0, 0);
+    __syncthreads();   // hipcc drains vmcnt(0) in front of the barrier: the DMA data has landed
 
     f32x4 acc[NI][NJ];
 #pragma unroll
@@ -136,58 +155,41 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
 
     int chunk = 0, tap = 0;
     for (int step = 0; step < nsteps; ++step) {
-        const bool more = step + 1 < nsteps;
-        const bool next_halo = chunk + 1 < a.nch;
-        // issue the global loads of the next step early; they are consumed after the MFMAs
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < WL; ++k) wreg[k] = *reinterpret_cast<const Slot*>(w_src(step + 1, tid + k * kConvThreads));
-        }
-        if (next_halo) {
-#pragma unroll
-            for (int k = 0; k < HL; ++k) {
-                const int s = (tap * HL + k) * kConvThreads + tid;
-                bool ok;
-                const char* src = halo_src(chunk + 1, s, ok);
-                hreg[k] = ok ? *reinterpret_cast<const Slot*>(src) : zero_slot();
-            }
-        }
-        // ---- MFMAs of this (chunk, tap) on the current buffers -------------------------------------
-        const char* hb = s_halo[chunk & 1];
-        const char* wb = s_w[step & 1];
+        // ---- fragments of this (chunk, tap) from the current buffers: all LDS reads of the step first ----
+        const char* hb = s_halo0 + (chunk & 1) * HBYTES;
+        const char* wb = s_w0 + (step & 1) * WBYTES;
         const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
+        Slot fa[2][NI], fb[2][NJ];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int slot = ks * 4 + g;
-            Slot fa[NI], fb[NJ];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int co = wco * WCO + i * 16 + l15;
-                fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
+                fa[ks][i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int hp = (wpx * NJ + j + ky) * HW_ + l15 + kx;
-                fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
+                fb[ks][j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
             }
+        }
+        // ---- DMA for the NEXT step: weights of (chunk,tap)+1 into the other weight buffer and one ninth of
+        //      the next K-row's halo into the other halo buffer.  Issued AFTER this step's LDS reads: hipcc
+        //      orders an LDS read behind any LDS-DMA still in flight (it waits vmcnt(0) in front of the read),
+        //      so reads placed after the issue would serialise the DMA with the MFMAs it is meant to hide under.
+        if (step + 1 < nsteps) stage_w(step + 1, (step + 1) & 1);
+        if (chunk + 1 < a.nch) stage_halo_part(chunk + 1, (chunk + 1) & 1, tap);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
-        }
-        // ---- retire the prefetched data into the other buffers ------------------------------------
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < WL; ++k) *reinterpret_cast<Slot*>(&s_w[(step + 1) & 1][(tid + k * kConvThreads) * 16]) = wreg[k];
-        }
-        if (next_halo) {
-#pragma unroll
-            for (int k = 0; k < HL; ++k) {
-                const int s = (tap * HL + k) * kConvThreads + tid;
-                if (s < HSLOTS) *reinterpret_cast<Slot*>(halo_dst((chunk + 1) & 1, s)) = hreg[k];
-            }
-        }
-        __syncthreads();
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[ks][i], fb[ks][j], acc[i][j]);
+        // keep the whole MFMA cluster in front of the DMA wait: without the fence hipcc hoists the barrier (and
+        // its vmcnt(0)) up between the first MFMAs, because register-only instructions may cross it
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();   // vmcnt(0) + barrier: next buffers are complete, current ones are free
         if (++tap == TAPS) { tap = 0; ++chunk; }
     }
 

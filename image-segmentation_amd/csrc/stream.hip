@@ -63,10 +63,6 @@ __global__ __launch_bounds__(kThreads) void im2col3x3_kernel(const float* __rest
 // ------------------------------------------------------------------------------ statistics
 // Block (b, g) sums its pixel range of group g for all channels.  partial layout:
 //   ws[((g*bpg + b)*2 + k)*C + c],  k = 0: sum, 1: sum of squares (or the two backward sums)
-struct RowSplit {
-    int cv, rows;  // channel vectors per pixel, pixel rows handled per block iteration
-};
-
 template <typename T, int MODE>  // MODE 0: sum x, sum x^2 ; MODE 1: column sum only
 __global__ __launch_bounds__(kThreads) void stats_partial_kernel(const T* __restrict__ x, int64_t ld, int64_t M, int C,
                                                                  int bpg, float* __restrict__ ws) {
@@ -99,19 +95,28 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(const T* __rest
     }
 }
 
-// mean / rstd per (group, channel) + optional running-buffer update (BatchNorm, groups == 1)
+// Fixed-order sum of the per-block partials of one (group, kind, channel): the 64 lanes of a wavefront take the
+// partials round-robin, then a butterfly adds the lanes (same order every run -> deterministic).
+__device__ __forceinline__ double wave_sum_partials(const float* __restrict__ ws, int64_t base, int64_t stride, int bpg) {
+    const int lane = threadIdx.x & 63;
+    double s = 0.0;
+    for (int b = lane; b < bpg; b += 64) s += (double)ws[base + (int64_t)b * stride];
+    return wave_sum_d(s);
+}
+
+// mean / rstd per (group, channel) + optional running-buffer update (BatchNorm, groups == 1).
+// One wavefront per channel (4 channels per block).
 __global__ __launch_bounds__(kThreads) void stats_finalize_kernel(const float* __restrict__ ws, int bpg, int64_t M, int C,
                                                                   float eps, float* __restrict__ stats,
                                                                   float* __restrict__ rmean, float* __restrict__ rvar,
                                                                   float momentum) {
     const int g = blockIdx.y;
-    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const int c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < bpg; ++b) {
-        s += (double)ws[(((int64_t)g * bpg + b) * 2 + 0) * C + c];
-        q += (double)ws[(((int64_t)g * bpg + b) * 2 + 1) * C + c];
-    }
+    const int64_t base = (int64_t)g * bpg * 2 * C + c;
+    const double s = wave_sum_partials(ws, base, 2 * (int64_t)C, bpg);
+    const double q = wave_sum_partials(ws, base + C, 2 * (int64_t)C, bpg);
+    if ((threadIdx.x & 63) != 0) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -134,11 +139,10 @@ __global__ __launch_bounds__(kThreads) void eval_stats_kernel(const float* __res
 
 __global__ __launch_bounds__(kThreads) void colsum_finalize_kernel(const float* __restrict__ ws, int bpg, int C,
                                                                    float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const int c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < bpg; ++b) s += (double)ws[((int64_t)b * 2 + 0) * C + c];
-    out[c] = accumulate ? out[c] + (float)s : (float)s;
+    const double s = wave_sum_partials(ws, c, 2 * (int64_t)C, bpg);
+    if ((threadIdx.x & 63) == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // ------------------------------------------------------------------------------ normalise (+ReLU)
@@ -226,18 +230,17 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __r
     }
 }
 
-// pass 1b: red[(g*C+c)*2 + {0,1}] = {s1, s2}; dgamma/dbeta; bias gradient of a frozen-statistics norm
+// pass 1b: red[(g*C+c)*2 + {0,1}] = {s1, s2}; dgamma/dbeta.  One wavefront per channel.
 __global__ __launch_bounds__(kThreads) void norm_bwd_finalize_kernel(const float* __restrict__ ws, int bpg, int C,
                                                                      float* __restrict__ red, float* __restrict__ dgamma,
                                                                      float* __restrict__ dbeta, int accumulate) {
     const int g = blockIdx.y;
-    const int c = blockIdx.x * kThreads + threadIdx.x;
+    const int c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < bpg; ++b) {
-        s1 += (double)ws[(((int64_t)g * bpg + b) * 2 + 0) * C + c];
-        s2 += (double)ws[(((int64_t)g * bpg + b) * 2 + 1) * C + c];
-    }
+    const int64_t base = (int64_t)g * bpg * 2 * C + c;
+    const double s1 = wave_sum_partials(ws, base, 2 * (int64_t)C, bpg);
+    const double s2 = wave_sum_partials(ws, base + C, 2 * (int64_t)C, bpg);
+    if ((threadIdx.x & 63) != 0) return;
     red[((int64_t)g * C + c) * 2 + 0] = (float)s1;
     red[((int64_t)g * C + c) * 2 + 1] = (float)s2;
     if (dgamma && g == 0) {
@@ -602,10 +605,10 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const T* __restrict_
 __global__ __launch_bounds__(kThreads) void head_bwd_finalize_kernel(const float* __restrict__ ws, int nblocks, int per,
                                                                      int split, float* __restrict__ dw,
                                                                      float* __restrict__ db) {
-    const int t = blockIdx.x * kThreads + threadIdx.x;
+    const int t = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
     if (t >= per) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)ws[(int64_t)b * per + t];
+    const double s = wave_sum_partials(ws, t, per, nblocks);
+    if ((threadIdx.x & 63) != 0) return;
     if (t < split) dw[t] = (float)s;
     else if (db) db[t - split] = (float)s;
 }
@@ -631,7 +634,7 @@ static int stats_bpg(int64_t groups, int64_t M, int64_t C) {
     // ~16 pixel rows of work per thread at least; cap total blocks near 4096
     const int64_t rows = kThreads / (C / 8);
     int64_t bpg = M / (rows * 16);
-    const int64_t cap = (4096 + groups - 1) / groups;
+    const int64_t cap = (2048 + groups - 1) / groups;
     if (bpg > cap) bpg = cap;
     if (bpg < 1) bpg = 1;
     return (int)bpg;
@@ -706,7 +709,7 @@ extern "C" int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t gro
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 0>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
                                                      (const T*)x, ld, M, (int)C, bpg, (float*)workspace));
     SEGK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads), (unsigned)groups), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)groups), dim3(kThreads), 0, st,
                        (const float*)workspace, bpg, M, (int)C, eps, stats, running_mean, running_var, momentum);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
@@ -761,7 +764,7 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_partial_kernel<T>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
                                                      (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, bpg, part));
     SEGK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads), (unsigned)groups), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)groups), dim3(kThreads), 0, st,
                        (const float*)part, bpg, (int)C, red, dgamma, dbeta, accumulate);
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
@@ -855,7 +858,7 @@ extern "C" int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int6
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 1>), dim3(bpg, 1), dim3(kThreads), 0, st, (const T*)x, ld, P,
                                                      (int)C, bpg, (float*)workspace));
     SEGK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(kThreads), 0, st,
                        (const float*)workspace, bpg, (int)C, out, (flags >> 1) & 1);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
@@ -926,7 +929,7 @@ extern "C" int segk_head1x1_bwd(int dtype, const void* x, int64_t ld, int64_t Ci
     if (rc != SEGK_OK) return rc;
     SEGK_LAUNCH_CHECK();
     const int per = (int)(Cout * Cin + Cout);
-    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3((per + kThreads - 1) / kThreads), dim3(kThreads), 0, st, (const float*)workspace, nb,
+    hipLaunchKernelGGL(head_bwd_finalize_kernel, dim3((per + 3) / 4), dim3(kThreads), 0, st, (const float*)workspace, nb,
                        per, (int)(Cout * Cin), dw, db);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
