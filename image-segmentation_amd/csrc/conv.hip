@@ -106,6 +106,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
     __shared__ __attribute__((aligned(16))) char smem[2 * HBYTES + 2 * WBYTES];
     char* const s_halo0 = smem;
     char* const s_w0 = smem + 2 * HBYTES;
+    const unsigned lds0 = lds_address(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
         for (int k = 0; k < HL; ++k) {
             const int qw = (part * HL + k) * kConvThreads + wave * 64;   // first slot of this wave's transfer
             const int q = qw + lane;
-            if (q < HSLOTS) glds16(halo_src(chunk, q), s_halo0 + buf * HBYTES + qw * 16);
+            if (q < HSLOTS) glds16_hidden(halo_src(chunk, q), lds0 + buf * HBYTES + qw * 16);
         }
     };
     auto stage_w = [&](int step, int buf) {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
 #pragma unroll
         for (int k = 0; k < WL; ++k) {
             const int qw = k * kConvThreads + wave * 64;
-            glds16(src + (int64_t)(qw + lane) * 16, s_w0 + buf * WBYTES + qw * 16);
+            glds16_hidden(src + (int64_t)(qw + lane) * 16, lds0 + 2 * HBYTES + buf * WBYTES + qw * 16);
         }
     };
 
@@ -161,7 +162,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
 #pragma unroll
     for (int part = 0; part < TAPS; ++part) stage_halo_part(0, 0, part);
     stage_w(0, 0);
-    __syncthreads();   // hipcc drains vmcnt(0) in front of the barrier: the DMA data has landed
+    dma_wait_all();
+    __syncthreads();
 
     f32x4 acc[NI][NJ];
 #pragma unroll
@@ -171,41 +173,42 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
 
     int chunk = 0, tap = 0;
     for (int step = 0; step < nsteps; ++step) {
-        // ---- fragments of this (chunk, tap) from the current buffers: all LDS reads of the step first ----
+        // DMA for the NEXT step goes out first (weights of (chunk,tap)+1 into the other weight buffer, one ninth of
+        // the next K-row's halo into the other halo buffer) and lands while this step is multiplied.
+        if (step + 1 < nsteps) stage_w(step + 1, (step + 1) & 1);
+        if (chunk + 1 < a.nch) stage_halo_part(chunk + 1, (chunk + 1) & 1, tap);
         const char* hb = s_halo0 + (chunk & 1) * HBYTES;
         const char* wb = s_w0 + (step & 1) * WBYTES;
         const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
-        Slot fa[2][NI], fb[2][NJ];
+        // a K-row whose second half holds no real channels (C = 32 in bf16, the 27-value patch row of the first
+        // convolution, the tail of a 96-channel concat) is multiplied with one k-substep instead of two
+        const int rc = chunk < a.nch0 ? a.C0 - chunk * KRow<T>::kElems : a.C1 - (chunk - a.nch0) * KRow<T>::kElems;
+        const int nks = rc > KRow<T>::kElems / 2 ? 2 : 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
+            if (ks >= nks) break;
             const int slot = ks * 4 + g;
+            Slot fa[NI], fb[NJ];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int co = wco * WCO + i * 16 + l15;
-                fa[ks][i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
+                fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int hp = (wpx * NJ + j + ky) * HW_ + l15 + kx;
-                fb[ks][j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
+                fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
             }
-        }
-        // ---- DMA for the NEXT step: weights of (chunk,tap)+1 into the other weight buffer and one ninth of
-        //      the next K-row's halo into the other halo buffer.  Issued AFTER this step's LDS reads: hipcc
-        //      orders an LDS read behind any LDS-DMA still in flight (it waits vmcnt(0) in front of the read),
-        //      so reads placed after the issue would serialise the DMA with the MFMAs it is meant to hide under.
-        if (step + 1 < nsteps) stage_w(step + 1, (step + 1) & 1);
-        if (chunk + 1 < a.nch) stage_halo_part(chunk + 1, (chunk + 1) & 1, tap);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[ks][i], fb[ks][j], acc[i][j]);
-        // keep the whole MFMA cluster in front of the DMA wait: without the fence hipcc hoists the barrier (and
-        // its vmcnt(0)) up between the first MFMAs, because register-only instructions may cross it
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        }
+        // keep the MFMA cluster in front of the DMA wait (register-only instructions may otherwise be moved
+        // across it), then: next buffers complete, current ones free
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();   // vmcnt(0) + barrier: next buffers are complete, current ones are free
+        dma_wait_all();
+        __syncthreads();
         if (++tap == TAPS) { tap = 0; ++chunk; }
     }
 
@@ -319,15 +322,18 @@ template <typename T> __device__ __forceinline__ int wg_swz(int pix);
 template <> __device__ __forceinline__ int wg_swz<bf16>(int pix) { return (((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2); }
 template <> __device__ __forceinline__ int wg_swz<float>(int pix) { return (pix & 1) << 2; }
 
-template <typename T, int TAPS>
+// TDI / TDJ: 16-wide tiles of the output-channel / input-channel side that hold real channels (a K-row has KR/16);
+// GI x GJ = 4: wave grid.  <4,4,2,2> is the square 64x64 block (bf16); <2,4,1,4> serves dy with <= 32 channels,
+// <4,2,4,1> an input K-row with <= 32 channels, without multiplying the zero half.
+template <typename T, int TAPS, int TDI, int TDJ, int GI, int GJ>
 __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int TH = 8;
     constexpr int PAD = TAPS == 9 ? 1 : 0;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_, TPIX = TH * kTW;
     constexpr int KR = KRow<T>::kElems;
     constexpr int EPS = 16 / (int)sizeof(T);
-    constexpr int TD = KR / 16;        // 16-wide tiles per block side: 4 (bf16) / 2 (fp32)
-    constexpr int WT = TD / 2;         // tiles per wave side (2x2 wave grid)
+    static_assert(GI * GJ == 4 && TDI % GI == 0 && TDJ % GJ == 0 && TDI <= KR / 16 && TDJ <= KR / 16, "bad wgrad tiling");
+    constexpr int WTI = TDI / GI, WTJ = TDJ / GJ;   // tiles per wave
     constexpr bool kBf16 = sizeof(T) == 2;
 
     constexpr int XBYTES = HPIX * kRowBytes, DBYTES = TPIX * kRowBytes;
@@ -337,7 +343,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
-    const int wi = wave >> 1, wj = wave & 1;
+    const int wi = wave / GJ, wj = wave % GJ;
 
     int b = blockIdx.x;
     const int split = b % a.splits; b /= a.splits;
@@ -350,13 +356,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
     const int xch = (s0 ? chunk : chunk - a.nch0) * KR;
     const int xcmax = s0 ? a.C0 : a.C1;
 
-    f32x4 acc[TAPS][WT][WT];
+    f32x4 acc[TAPS][WTI][WTJ];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTI; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < WTJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int ntiles = a.N * a.tiles_y * a.tiles_x;
     const int t_lo = split * a.tiles_per_split;
@@ -416,13 +422,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 #pragma unroll 1
             for (int kk = 0; kk < TPIX / 32; ++kk) {
-                s16x8 fa[WT];
+                s16x8 fa[WTI];
                 int kpix[2];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) kpix[h] = kk * 32 + 8 * g + q + 4 * h;
 #pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    const int u = (wi * WT + i) * 4 + p;
+                for (int i = 0; i < WTI; ++i) {
+                    const int u = (wi * WTI + i) * 4 + p;
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int pix = kpix[h];
@@ -435,8 +441,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                 for (int t = 0; t < TAPS; ++t) {
                     const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
 #pragma unroll
-                    for (int j = 0; j < WT; ++j) {
-                        const int u = (wj * WT + j) * 4 + p;
+                    for (int j = 0; j < WTJ; ++j) {
+                        const int u = (wj * WTJ + j) * 4 + p;
                         s16x8 fb;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                             fb[4 * h + 0] = r[0]; fb[4 * h + 1] = r[1]; fb[4 * h + 2] = r[2]; fb[4 * h + 3] = r[3];
                         }
 #pragma unroll
-                        for (int i = 0; i < WT; ++i)
+                        for (int i = 0; i < WTI; ++i)
                             acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
                                                                                   __builtin_bit_cast(bf16x8, fb), acc[t][i][j], 0, 0, 0);
                     }
@@ -457,10 +463,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 #pragma unroll 1
             for (int kk = 0; kk < TPIX / 4; ++kk) {
                 const int pix = kk * 4 + g;
-                float fa[WT];
+                float fa[WTI];
 #pragma unroll
-                for (int i = 0; i < WT; ++i) {
-                    const int c = (wi * WT + i) * 16 + l15;
+                for (int i = 0; i < WTI; ++i) {
+                    const int c = (wi * WTI + i) * 16 + l15;
                     fa[i] = *reinterpret_cast<const float*>(&s_dy[pix * kRowBytes + ((((c >> 2) ^ wg_swz<T>(pix)) << 4) | ((c & 3) << 2))]);
                 }
 #pragma unroll
@@ -468,11 +474,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                     const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
                     const int hp = ((pix >> 4) + ky) * HW_ + (pix & 15) + kx;
 #pragma unroll
-                    for (int j = 0; j < WT; ++j) {
-                        const int c = (wj * WT + j) * 16 + l15;
+                    for (int j = 0; j < WTJ; ++j) {
+                        const int c = (wj * WTJ + j) * 16 + l15;
                         const float fb = *reinterpret_cast<const float*>(&s_x[hp * kRowBytes + ((((c >> 2) ^ wg_swz<T>(hp)) << 4) | ((c & 3) << 2))]);
 #pragma unroll
-                        for (int i = 0; i < WT; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb, acc[t][i][j], 0, 0, 0);
+                        for (int i = 0; i < WTI; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb, acc[t][i][j], 0, 0, 0);
                     }
                 }
             }
@@ -489,13 +495,13 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 #pragma unroll
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTI; ++i)
 #pragma unroll
-            for (int j = 0; j < WT; ++j) {
-                const int ci = chunk * KR + (wj * WT + j) * 16 + l15;
+            for (int j = 0; j < WTJ; ++j) {
+                const int ci = chunk * KR + (wj * WTJ + j) * 16 + l15;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = cb * KR + (wi * WT + i) * 16 + 4 * g + r;
+                    const int co = cb * KR + (wi * WTI + i) * 16 + 4 * g + r;
                     a.slab[(((int64_t)split * co_tot + co) * TAPS + t) * cin_tot + ci] = acc[t][i][j][r];
                 }
             }
@@ -526,13 +532,21 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const f
 // ------------------------------------------------------------------------------------------------
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 static inline int krow(int dtype) { return dtype == SEGK_BF16 ? 64 : 32; }
-static inline int pick_bn(int64_t cout_pad) { return cout_pad % 128 == 0 ? 128 : (cout_pad % 64 == 0 ? 64 : 32); }
+// output channels per workgroup: as wide as divides the (32-padded) channel count, so that the input halo is
+// staged as few times as possible; 96 serves the 96- and 192-channel data gradients of the concat inputs
+static inline int pick_bn(int64_t cout_pad) {
+    if (cout_pad % 128 == 0) return 128;
+    if (cout_pad % 96 == 0) return 96;
+    return cout_pad % 64 == 0 ? 64 : 32;
+}
 
 template <typename T, int TAPS>
 static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
     const unsigned grid = (unsigned)((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn));
     if (bn == 128)
         hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 128, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
+    else if (bn == 96)
+        hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 96, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else if (bn == 64)
         hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 64, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else
@@ -670,8 +684,23 @@ extern "C" int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0,
     a.slab = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
-    if (taps == 9) SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_wgrad_kernel<T, 9>), dim3(grid), dim3(kConvThreads), 0, st, a));
-    else SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_wgrad_kernel<T, 1>), dim3(grid), dim3(kConvThreads), 0, st, a));
+    // tiling variant: skip the zero half of a 64-channel bf16 K-row when dy (or a single-K-row input) has <= 32 channels
+    const bool thin_co = dtype == SEGK_BF16 && Cout <= 32;
+    const bool thin_ci = dtype == SEGK_BF16 && !thin_co && a.nch == 1 && C0 <= 32;
+#define SEGK_WG(TAPS_)                                                                                                   \
+    do {                                                                                                                 \
+        if (dtype == SEGK_F32)                                                                                           \
+            hipLaunchKernelGGL((conv_wgrad_kernel<float, TAPS_, 2, 2, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a); \
+        else if (thin_co)                                                                                                \
+            hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS_, 2, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);  \
+        else if (thin_ci)                                                                                                \
+            hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS_, 4, 2, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);  \
+        else                                                                                                             \
+            hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS_, 4, 4, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);  \
+    } while (0)
+    if (taps == 9) SEGK_WG(9);
+    else SEGK_WG(1);
+#undef SEGK_WG
     SEGK_LAUNCH_CHECK();
     const int64_t total = Cout * cin_real * taps;
     int64_t rgrid = (total + kConvThreads - 1) / kConvThreads;

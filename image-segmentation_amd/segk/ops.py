@@ -109,9 +109,10 @@ def _p(t):
 
 # ------------------------------------------------------------------------------------ layout
 def im2col3x3(x, dtype):
-    """[N,Cin,H,W] fp32 -> NHWC patch image with one K-row of channels (9*Cin real ones)."""
+    """[N,Cin,H,W] fp32 -> NHWC patch image with 32 channels (9*Cin real ones, the rest zero): half a bf16
+    K-row, so the convolution multiplies it with a single k-substep."""
     N, Cin, H, W = x.shape
-    C = krow(dtype)
+    C = 32
     assert 9 * Cin <= C, "im2col path is for few-channel inputs"
     x = x.contiguous().float()
     out = Act.empty(N, H, W, C, dtype, x.device)

@@ -41,7 +41,9 @@ CONV_CASES = [
     (1, 24, 40, 128, 128),    # tiles not filling the image; BN=128 path
     (2, 12, 12, 96, 32),      # partial K-row (bf16), BN=32 path, image smaller than a tile
     (1, 32, 48, 32, 256),
-    (3, 8, 16, 192, 96),      # BN=32 with 3 channel blocks
+    (3, 8, 16, 192, 96),      # 96-wide channel block
+    (1, 16, 32, 32, 96),      # half K-row input (single k-substep); data gradient with 32 output channels
+    (1, 16, 16, 128, 192),    # two 96-wide channel blocks
 ]
 
 
