@@ -14,6 +14,7 @@
 // MFMA orientation (forward): A = weights (rows = output channels), B = pixels (columns), so a lane's
 // four accumulator registers are four CONSECUTIVE output channels of one pixel -> one 8/16-byte store.
 #include "common.h"
+#include <stdlib.h>
 
 namespace segk {
 
@@ -554,9 +555,11 @@ static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
 }
 
 static int wgrad_splits(int64_t ntiles, int64_t ncb, int64_t nch) {
-    // Two workgroups fit a CU (LDS), so ~512 are resident at once; about three rounds of them balance the tail
-    // best (measured: 640 in total is 8 % slower over the UNet-VGG layers despite the smaller partial-slab traffic).
-    int64_t s = (1536 + ncb * nch - 1) / (ncb * nch);
+    // Two workgroups fit a CU (LDS and registers), so 512 are resident at once.  Exactly one resident round has
+    // no tail and keeps the partial-slab traffic (147 KB written and read back per workgroup) at its minimum;
+    // `target` can be overridden for experiments.
+    static const int64_t target = getenv("SEGK_WGRAD_BLOCKS") ? atoll(getenv("SEGK_WGRAD_BLOCKS")) : 512;
+    int64_t s = target / (ncb * nch);
     if (s > ntiles) s = ntiles;
     if (s > 512) s = 512;
     if (s < 1) s = 1;
