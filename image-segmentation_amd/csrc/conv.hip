@@ -85,6 +85,8 @@ __device__ __forceinline__ void glds16_hidden(const char* src, unsigned lds_addr
                  : "memory");
 }
 __device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// wait until at most N of this wave's youngest vector-memory operations are still in flight
+template <int N> __device__ __forceinline__ void dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ __forceinline__ unsigned lds_address(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
@@ -101,7 +103,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
     constexpr int NI = WCO / 16, NJ = WPX / 16;
     static_assert(WPX_WAVES * WCO_WAVES == 4 && NI >= 1 && NJ >= 1, "bad wave layout");
     constexpr int EPS = 16 / (int)sizeof(T);   // elements per 16-byte slot
-    constexpr int HBYTES = HPIX * kRowBytes, WBYTES = BN * kRowBytes;
+    // the halo of a K-row is moved in HPARTS parts of HL transfers per thread, one part per tap; the buffer is padded
+    // to whole parts so that every wave issues every transfer (the counted DMA wait relies on equal counts)
+    constexpr int HPARTS = (HSLOTS + HL * kConvThreads - 1) / (HL * kConvThreads);
+    static_assert(HPARTS <= TAPS, "halo parts must fit the taps of a K-row");
+    constexpr int HBYTES = HPARTS * HL * kConvThreads * 16, WBYTES = BN * kRowBytes;
 
     // one LDS object: [halo 0 | halo 1 | weights 0 | weights 1]
     __shared__ __attribute__((aligned(16))) char smem[2 * HBYTES + 2 * WBYTES];
@@ -127,41 +133,48 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
     // ---- staging: global -> LDS by DMA (no registers, stays in flight behind the MFMAs) -------------
     // LDS slot q of the halo image holds pixel q>>3, and -- because the DMA destination is linear in the
     // lane index -- the swizzle is applied to the SOURCE: slot q receives channel slot (q&7) ^ (pixel&7).
-    // Padding (outside the image, past the segment's channels) reads the 16 zero bytes of kZeroSlot.
-    auto halo_src = [&](int chunk, int q) -> const char* {
+    // Padding (outside the image, past the segment's channels, the pad slots behind the halo) reads the 16 zero
+    // bytes of kZeroSlot.  The slot -> pixel arithmetic does not depend on the K-row, so every thread keeps, for
+    // each of its HPARTS*HL transfers per K-row, (pixel index << 3 | channel slot) or -1 in a register.
+    int hinfo[HPARTS * HL];
+#pragma unroll
+    for (int p = 0; p < HPARTS * HL; ++p) {
+        const int q = p * kConvThreads + tid;
         const int pix = q >> 3, sl = (q & 7) ^ (pix & 7);
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
+        const bool in = q < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hinfo[p] = in ? ((((n * a.H + gy) * a.W + gx) << 3) | sl) : -1;
+    }
+    // transfers of halo part `part` (HL per thread) of K-row `chunk` into halo buffer `buf`
+    auto stage_halo_part = [&](int chunk, int buf, int part) {
         const bool s0 = chunk < a.nch0;
         const char* base = s0 ? a.x0 : a.x1;
         const int64_t ld = s0 ? a.ld0 : a.ld1;
-        const int ch = (s0 ? chunk : chunk - a.nch0) * KRow<T>::kElems + sl * EPS;
-        const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ch < (s0 ? a.C0 : a.C1);
-        const int64_t off = ((((int64_t)n * a.H + gy) * a.W + gx) * ld + ch) * (int64_t)sizeof(T);
-        return ok ? base + off : reinterpret_cast<const char*>(&kZeroSlot);
-    };
-    auto stage_halo_part = [&](int chunk, int buf, int part) {
+        const int ch0 = (s0 ? chunk : chunk - a.nch0) * KRow<T>::kElems;
+        const int cmax = s0 ? a.C0 : a.C1;
 #pragma unroll
         for (int k = 0; k < HL; ++k) {
-            const int qw = (part * HL + k) * kConvThreads + wave * 64;   // first slot of this wave's transfer
-            const int q = qw + lane;
-            if (q < HSLOTS) glds16_hidden(halo_src(chunk, q), lds0 + buf * HBYTES + qw * 16);
+            const int info = hinfo[part * HL + k];
+            const int ch = ch0 + (info & 7) * EPS;
+            const bool ok = info >= 0 && ch < cmax;
+            const char* src = ok ? base + ((int64_t)(info >> 3) * ld + ch) * (int64_t)sizeof(T) : reinterpret_cast<const char*>(&kZeroSlot);
+            glds16_hidden(src, lds0 + buf * HBYTES + ((part * HL + k) * kConvThreads + wave * 64) * 16);
         }
     };
+    const char* const wsrc0 = a.w + (int64_t)cb * BN * kRowBytes + (int64_t)tid * 16;
     auto stage_w = [&](int step, int buf) {
-        const char* src = a.w + (((int64_t)step * a.cout_pad + (int64_t)cb * BN) * kRowBytes);
+        const char* src = wsrc0 + (int64_t)step * a.cout_pad * kRowBytes;
 #pragma unroll
-        for (int k = 0; k < WL; ++k) {
-            const int qw = k * kConvThreads + wave * 64;
-            glds16_hidden(src + (int64_t)(qw + lane) * 16, lds0 + 2 * HBYTES + buf * WBYTES + qw * 16);
-        }
+        for (int k = 0; k < WL; ++k)
+            glds16_hidden(src + k * kConvThreads * 16, lds0 + 2 * HBYTES + buf * WBYTES + (k * kConvThreads + wave * 64) * 16);
     };
 
     const int nsteps = a.nch * TAPS;
 
     // ---- prologue: whole halo of K-row 0 and the weights of step 0 -----------------------------------
 #pragma unroll
-    for (int part = 0; part < TAPS; ++part) stage_halo_part(0, 0, part);
+    for (int part = 0; part < HPARTS; ++part) stage_halo_part(0, 0, part);
     stage_w(0, 0);
     dma_wait_all();
     __syncthreads();
@@ -172,45 +185,58 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int chunk = 0, tap = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        // DMA for the NEXT step goes out first (weights of (chunk,tap)+1 into the other weight buffer, one ninth of
-        // the next K-row's halo into the other halo buffer) and lands while this step is multiplied.
-        if (step + 1 < nsteps) stage_w(step + 1, (step + 1) & 1);
-        if (chunk + 1 < a.nch) stage_halo_part(chunk + 1, (chunk + 1) & 1, tap);
-        const char* hb = s_halo0 + (chunk & 1) * HBYTES;
-        const char* wb = s_w0 + (step & 1) * WBYTES;
-        const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
+    // per-lane LDS read bases; everything tap-dependent below is a compile-time offset (taps are unrolled)
+    const int co_l = wco * WCO + l15, hp_l = wpx * NJ * HW_ + l15;
+
+    for (int chunk = 0; chunk < a.nch; ++chunk) {
         // a K-row whose second half holds no real channels (C = 32 in bf16, the 27-value patch row of the first
         // convolution, the tail of a 96-channel concat) is multiplied with one k-substep instead of two
         const int rc = chunk < a.nch0 ? a.C0 - chunk * KRow<T>::kElems : a.C1 - (chunk - a.nch0) * KRow<T>::kElems;
         const int nks = rc > KRow<T>::kElems / 2 ? 2 : 1;
+        const bool next_chunk = chunk + 1 < a.nch;
+        const char* hb = s_halo0 + (chunk & 1) * HBYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            if (ks >= nks) break;
-            const int slot = ks * 4 + g;
-            Slot fa[NI], fb[NJ];
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int step = chunk * TAPS + tap;
+            // DMA for later steps goes out first: the weights of the NEXT (K-row, tap) into the other weight buffer,
+            // then one part of the NEXT K-row's halo into the other halo buffer.  Issue order matters: the wait at
+            // the end of the step leaves the (younger) halo transfers in flight, so their HBM latency is spread
+            // over the remaining taps of the K-row instead of being paid every step.
+            if (step + 1 < nsteps) stage_w(step + 1, (step + 1) & 1);
+            const bool halo_now = tap < HPARTS && next_chunk;
+            if (halo_now) stage_halo_part(chunk + 1, (chunk + 1) & 1, tap);
+            const char* wb = s_w0 + (step & 1) * WBYTES;
+            constexpr int kyx = 0;
+            (void)kyx;
+            const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int co = wco * WCO + i * 16 + l15;
-                fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
+            for (int ks = 0; ks < 2; ++ks) {
+                if (ks >= nks) break;
+                const int slot = ks * 4 + g;
+                Slot fa[NI], fb[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int co = co_l + i * 16;
+                    fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int hp = hp_l + (j + ky) * HW_ + kx;
+                    fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
             }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int hp = (wpx * NJ + j + ky) * HW_ + l15 + kx;
-                fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+            // keep the MFMA cluster in front of the DMA wait (register-only instructions may otherwise be moved
+            // across it).  Wait for everything but this step's halo transfers (the last tap of a K-row waits for
+            // all: the next K-row reads that halo), then: next weight buffer complete, current buffers free.
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap == TAPS - 1 || !halo_now) dma_wait_all();
+            else dma_wait_but<HL>();
+            __syncthreads();
         }
-        // keep the MFMA cluster in front of the DMA wait (register-only instructions may otherwise be moved
-        // across it), then: next buffers complete, current ones free
-        __builtin_amdgcn_sched_barrier(0);
-        dma_wait_all();
-        __syncthreads();
-        if (++tap == TAPS) { tap = 0; ++chunk; }
     }
 
     // ---- epilogue: bias, ReLU, mask, store 4 consecutive channels per lane --------------------------
