@@ -398,36 +398,50 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 
     // Stage one spatial tile (input halo + output-gradient tile) into LDS stage `st` by DMA.  The LDS image is
     // linear in the lane index, so the bank swizzle is applied to the SOURCE: slot q = (pixel, s') receives channel
-    // slot s' ^ swz(pixel).  Padding reads the 16 zero bytes of kZeroSlot.
+    // slot s' ^ swz(pixel).  Padding reads the 16 zero bytes of kZeroSlot.  The slot -> (row, column, channel slot)
+    // arithmetic is tile-independent and kept in registers: hy<<16 | hx<<8 | channel offset, or -1 for "no slot".
+    constexpr int XL = (HPIX * 8 + kConvThreads - 1) / kConvThreads, DL = TPIX * 8 / kConvThreads;
+    int xinfo[XL], dinfo[DL];
+#pragma unroll
+    for (int k = 0; k < XL; ++k) {
+        const int q = k * kConvThreads + tid;
+        const int pix = q >> 3, sl = (q & 7) ^ wg_swz<T>(pix);
+        const int hy = pix / HW_, hx = pix - hy * HW_;
+        xinfo[k] = (q < HPIX * 8 && xch + sl * EPS < xcmax) ? ((hy << 16) | (hx << 8) | (sl * EPS)) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < DL; ++k) {
+        const int q = k * kConvThreads + tid;
+        const int pix = q >> 3, sl = (q & 7) ^ wg_swz<T>(pix);
+        dinfo[k] = (cb * KR + sl * EPS < a.Cout) ? (((pix >> 4) << 16) | ((pix & 15) << 8) | (sl * EPS)) : -1;
+    }
+    const char* const xsrc0 = xbase + (int64_t)xch * (int64_t)sizeof(T);
+    const char* const dsrc0 = a.dy + (int64_t)cb * KR * (int64_t)sizeof(T);
     auto stage = [&](int tile, int st) {
         int sp = tile;
         const int tx = sp % a.tiles_x; sp /= a.tiles_x;
         const int ty = sp % a.tiles_y;
         const int n = sp / a.tiles_y;
-        const int y0 = ty * TH, x0 = tx * kTW;
+        const int y0 = ty * TH - PAD, x0 = tx * kTW - PAD;
         const unsigned xdst = lds0 + st * (XBYTES + DBYTES), ddst = xdst + XBYTES;
-        for (int qw = wave * 64; qw < HPIX * 8; qw += kConvThreads) {
-            const int q = qw + lane;
-            if (q < HPIX * 8) {
-                const int pix = q >> 3, sl = (q & 7) ^ wg_swz<T>(pix);
-                const int hy = pix / HW_, hx = pix - hy * HW_;
-                const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
-                const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && xch + sl * EPS < xcmax;
-                const char* src = ok ? xbase + ((((int64_t)n * a.H + gy) * a.W + gx) * ldx + xch + sl * EPS) * (int64_t)sizeof(T)
-                                     : reinterpret_cast<const char*>(&kZeroSlot);
-                glds16_hidden(src, xdst + qw * 16);
-            }
+#pragma unroll
+        for (int k = 0; k < XL; ++k) {
+            const int info = xinfo[k];
+            const int gy = y0 + (info >> 16), gx = x0 + ((info >> 8) & 255);
+            const bool ok = info >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const char* src = ok ? xsrc0 + ((((int64_t)n * a.H + gy) * a.W + gx) * ldx + (info & 255)) * (int64_t)sizeof(T)
+                                 : reinterpret_cast<const char*>(&kZeroSlot);
+            // the last transfer of the halo is partial: lanes past the image's end are masked off
+            if (k * kConvThreads + tid < HPIX * 8) glds16_hidden(src, xdst + (k * kConvThreads + wave * 64) * 16);
         }
 #pragma unroll
-        for (int qw = wave * 64; qw < TPIX * 8; qw += kConvThreads) {
-            const int q = qw + lane;
-            const int pix = q >> 3, sl = (q & 7) ^ wg_swz<T>(pix);
-            const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-            const int ch = cb * KR + sl * EPS;
-            const bool ok = gy < a.H && gx < a.W && ch < a.Cout;
-            const char* src = ok ? a.dy + ((((int64_t)n * a.H + gy) * a.W + gx) * a.ldy + ch) * (int64_t)sizeof(T)
+        for (int k = 0; k < DL; ++k) {
+            const int info = dinfo[k];
+            const int gy = y0 + PAD + (info >> 16), gx = x0 + PAD + ((info >> 8) & 255);
+            const bool ok = info >= 0 && gy < a.H && gx < a.W;
+            const char* src = ok ? dsrc0 + ((((int64_t)n * a.H + gy) * a.W + gx) * a.ldy + (info & 255)) * (int64_t)sizeof(T)
                                  : reinterpret_cast<const char*>(&kZeroSlot);
-            glds16_hidden(src, ddst + qw * 16);
+            glds16_hidden(src, ddst + (k * kConvThreads + wave * 64) * 16);
         }
     };
 
