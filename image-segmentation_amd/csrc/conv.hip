@@ -26,7 +26,18 @@ template <typename T> struct KRow { static constexpr int kElems = kRowBytes / (i
 
 typedef uint4 Slot;   // 16 bytes
 
+// A strided window onto an NHWC image: logical pixel (y, x) of the convolution grid is physical pixel
+// (y*sy + oy, x*sx + ox) of an image with PH x PW pixels.  Identity for ordinary convolutions; the four
+// phases of a stride-2 transposed convolution read/write every other row and column.
+struct View {
+    int PH, PW, sy, sx, oy, ox;
+    __device__ __forceinline__ int pixel(int n, int y, int x) const { return (n * PH + y * sy + oy) * PW + x * sx + ox; }
+};
+static inline View identity_view(int H, int W) { return View{H, W, 1, 1, 0, 0}; }
+
 struct ConvArgs {
+    View vin, vout;                   // windows of the input segments / of the output (and mask)
+    int tky[9], tkx[9];               // tap offsets + 1 (used when TAPS == 4; 9 and 1 are compile-time)
     const char* x0; const char* x1;   // input segments (bytes)
     int64_t ld0, ld1;                 // pixel strides in elements
     int C0, C1;                       // channels of each segment (a last partial K-row is zero-filled)
@@ -93,7 +104,7 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 
 template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES>
 __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a) {
-    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int PAD = TAPS == 1 ? 0 : 1;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_;
     constexpr int HSLOTS = HPIX * 8;
     constexpr int HL = (HSLOTS + TAPS * kConvThreads - 1) / (TAPS * kConvThreads);   // halo transfers / thread / step
@@ -144,7 +155,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
         const bool in = q < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        hinfo[p] = in ? ((((n * a.H + gy) * a.W + gx) << 3) | sl) : -1;
+        hinfo[p] = in ? ((a.vin.pixel(n, gy, gx) << 3) | sl) : -1;
     }
     // transfers of halo part `part` (HL per thread) of K-row `chunk` into halo buffer `buf`
     auto stage_halo_part = [&](int chunk, int buf, int part) {
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
             const char* wb = s_w0 + (step & 1) * WBYTES;
             constexpr int kyx = 0;
             (void)kyx;
-            const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
+            const int ky = TAPS == 9 ? tap / 3 : (TAPS == 4 ? a.tky[tap] : 0), kx = TAPS == 9 ? tap % 3 : (TAPS == 4 ? a.tkx[tap] : 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 if (ks >= nks) break;
@@ -244,7 +255,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
     for (int j = 0; j < NJ; ++j) {
         const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
         if (yy >= a.H || xx >= a.W) continue;
-        const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+        const int64_t pix = a.vout.pixel(n, yy, xx);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int co = cb * BN + wco * WCO + i * 16 + 4 * g;
@@ -328,12 +339,64 @@ __global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __
 }
 
 // ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(kernel 4, stride 2, padding 1) as four phase convolutions.  Output pixel (2m+a, 2n+b) only
+// sees kernel rows ky with ky = a+1 (input row m) or ky = 3 (a=0, row m-1) / ky = 0 (a=1, row m+1), likewise for
+// columns: every phase (a,b) is a 2x2-tap convolution over the INPUT grid whose result is written to every other
+// output row/column.  Tap t = ty*2+tx of phase (a,b): input offset (dy,dx), kernel element (ky,kx).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int ct_off(int a, int t) { return t == 0 ? 0 : (a == 0 ? -1 : 1); }
+__host__ __device__ inline int ct_k(int a, int t) { return t == 0 ? 1 + a : (a == 0 ? 3 : 0); }
+
+// weight [Cin][Cout][4][4] fp32 -> per phase: forward image (rows = Cout, K = Cin) and data-gradient image
+// (rows = Cin, K = Cout), both [K-row][4 taps][rows][128 B] swizzled like conv_pack_kernel's
+template <typename T>
+__global__ __launch_bounds__(kConvThreads) void convt_pack_kernel(const float* __restrict__ w, int Cin, int Cout,
+                                                                  char* __restrict__ wf, char* __restrict__ wb) {
+    constexpr int EPS = 16 / (int)sizeof(T);
+    constexpr int KR = KRow<T>::kElems;
+    const int rows_f = (Cout + 31) / 32 * 32, kf = (Cin + KR - 1) / KR * KR;
+    const int rows_b = (Cin + 31) / 32 * 32, kb = (Cout + KR - 1) / KR * KR;
+    const int64_t per_f = (int64_t)(kf / KR) * 4 * rows_f * 8, per_b = (int64_t)(kb / KR) * 4 * rows_b * 8;
+    const int64_t nf = wf ? 4 * per_f : 0, nb = wb ? 4 * per_b : 0;
+    for (int64_t i = (int64_t)blockIdx.x * kConvThreads + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * kConvThreads) {
+        const bool fwd = i < nf;
+        int64_t r = fwd ? i : i - nf;
+        const int64_t per = fwd ? per_f : per_b;
+        const int phase = (int)(r / per); r -= phase * per;
+        const int sl = (int)(r & 7); r >>= 3;
+        const int rows = fwd ? rows_f : rows_b;
+        const int row = (int)(r % rows); r /= rows;
+        const int tap = (int)(r & 3);
+        const int chunk = (int)(r >> 2);
+        const int ky = ct_k(phase >> 1, tap >> 1), kx = ct_k(phase & 1, tap & 1);
+        float v[EPS];
+#pragma unroll
+        for (int j = 0; j < EPS; ++j) {
+            const int k = chunk * KR + sl * EPS + j;
+            const int co = fwd ? row : k, ci = fwd ? k : row;
+            v[j] = (co < Cout && ci < Cin) ? w[(((int64_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.f;
+        }
+        char* dst = (fwd ? wf : wb) + ((int64_t)phase * per + (((int64_t)chunk * 4 + tap) * rows + row) * 8) * 16 + ((sl ^ (row & 7)) << 4);
+        if constexpr (sizeof(T) == 2) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+            *reinterpret_cast<bf16x8*>(dst) = o;
+        } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight-gradient kernel.  Workgroup = (output-channel block of one K-row width, input K-row, pixel
 // split).  Both MFMA operands are needed "pixel-major" (K = pixels) while memory is channel-major;
 // for bf16 the transposing LDS read ds_read_b64_tr_b16 delivers exactly the A/B fragment layout from
 // the [pixel][channel] image, for fp32 a lane reads single elements.
 // ------------------------------------------------------------------------------------------------
 struct WgradArgs {
+    View vdy;                 // window of dy (identity, or one phase of a transposed convolution's output gradient)
+    int tky[9], tkx[9];       // tap offsets + 1 when TAPS == 4
     const char* x0; const char* x1;
     int64_t ld0, ld1;
     int C0, C1;
@@ -355,7 +418,7 @@ template <> __device__ __forceinline__ int wg_swz<float>(int pix) { return (pix 
 template <typename T, int TAPS, int TDI, int TDJ, int GI, int GJ>
 __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int TH = 8;
-    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int PAD = TAPS == 1 ? 0 : 1;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_, TPIX = TH * kTW;
     constexpr int KR = KRow<T>::kElems;
     constexpr int EPS = 16 / (int)sizeof(T);
@@ -439,7 +502,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
             const int info = dinfo[k];
             const int gy = y0 + PAD + (info >> 16), gx = x0 + PAD + ((info >> 8) & 255);
             const bool ok = info >= 0 && gy < a.H && gx < a.W;
-            const char* src = ok ? dsrc0 + ((((int64_t)n * a.H + gy) * a.W + gx) * a.ldy + (info & 255)) * (int64_t)sizeof(T)
+            const char* src = ok ? dsrc0 + ((int64_t)a.vdy.pixel(n, gy, gx) * a.ldy + (info & 255)) * (int64_t)sizeof(T)
                                  : reinterpret_cast<const char*>(&kZeroSlot);
             glds16_hidden(src, ddst + (k * kConvThreads + wave * 64) * 16);
         }
@@ -480,7 +543,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                 }
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
-                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                    const int ky = TAPS == 9 ? t / 3 : (TAPS == 4 ? a.tky[t] : 0), kx = TAPS == 9 ? t % 3 : (TAPS == 4 ? a.tkx[t] : 0);
 #pragma unroll
                     for (int j = 0; j < WTJ; ++j) {
                         const int u = (wj * WTJ + j) * 4 + p;
@@ -512,7 +575,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                 }
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
-                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                    const int ky = TAPS == 9 ? t / 3 : (TAPS == 4 ? a.tky[t] : 0), kx = TAPS == 9 ? t % 3 : (TAPS == 4 ? a.tkx[t] : 0);
                     const int hp = ((pix >> 4) + ky) * HW_ + (pix & 15) + kx;
 #pragma unroll
                     for (int j = 0; j < WTJ; ++j) {
@@ -552,7 +615,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t co_tot,
                                                                          int taps, int cin_tot, int cout_real, int cin_real,
                                                                          int seg0, int k0_pad, float* __restrict__ dw,
-                                                                         int accumulate) {
+                                                                         int accumulate, int ct_cout, int ct_k0, int ct_k1,
+                                                                         int ct_k2, int ct_k3) {
     const int64_t total = (int64_t)cout_real * cin_real * taps;
     for (int64_t i = (int64_t)blockIdx.x * kConvThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kConvThreads) {
         // iterate with ci fastest so that slab reads are coalesced
@@ -563,7 +627,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const f
         const int kc = ci < seg0 ? ci : k0_pad + (ci - seg0);   // position in the K-row-padded channel space
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += slab[(((int64_t)k * co_tot + co) * taps + t) * cin_tot + kc];
-        float* d = dw + ((int64_t)co * cin_real + ci) * taps + t;
+        // ordinary convolution: OIHW [co][ci][tap].  Transposed convolution (ct_cout > 0): the weight is
+        // [ci][co][4][4] and tap t of this phase is kernel element ct_k{t}.
+        float* d = ct_cout > 0 ? dw + ((int64_t)ci * ct_cout + co) * 16 + (t == 0 ? ct_k0 : t == 1 ? ct_k1 : t == 2 ? ct_k2 : ct_k3)
+                               : dw + ((int64_t)co * cin_real + ci) * taps + t;
         *d = accumulate ? *d + s : s;
     }
 }
@@ -594,6 +661,18 @@ static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
         hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 32, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);
 }
 
+static void launch_fwd_any(int dtype, int taps, const ConvArgs& a, int bn, hipStream_t st) {
+    if (dtype == SEGK_BF16) {
+        if (taps == 9) launch_fwd_t<bf16, 9>(a, bn, st);
+        else if (taps == 4) launch_fwd_t<bf16, 4>(a, bn, st);
+        else launch_fwd_t<bf16, 1>(a, bn, st);
+    } else {
+        if (taps == 9) launch_fwd_t<float, 9>(a, bn, st);
+        else if (taps == 4) launch_fwd_t<float, 4>(a, bn, st);
+        else launch_fwd_t<float, 1>(a, bn, st);
+    }
+}
+
 static int wgrad_splits(int64_t ntiles, int64_t ncb, int64_t nch) {
     // Two workgroups fit a CU (LDS and registers), so 512 are resident at once.  Exactly one resident round has
     // no tail and keeps the partial-slab traffic (147 KB written and read back per workgroup) at its minimum;
@@ -606,6 +685,26 @@ static int wgrad_splits(int64_t ntiles, int64_t ncb, int64_t nch) {
     // even out the tile ranges
     const int64_t per = (ntiles + s - 1) / s;
     return (int)((ntiles + per - 1) / per);
+}
+
+template <int TAPS>
+static void launch_wgrad_t(int dtype, const WgradArgs& a, unsigned grid, hipStream_t st, int64_t Cout, int64_t C0) {
+    // tiling variant: skip the zero half of a 64-channel bf16 K-row when dy (or a single-K-row input) has <= 32 channels
+    const bool thin_co = dtype == SEGK_BF16 && Cout <= 32;
+    const bool thin_ci = dtype == SEGK_BF16 && !thin_co && a.nch == 1 && C0 <= 32;
+    if (dtype == SEGK_F32)
+        hipLaunchKernelGGL((conv_wgrad_kernel<float, TAPS, 2, 2, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
+    else if (thin_co)
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS, 2, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
+    else if (thin_ci)
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS, 4, 2, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);
+    else
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS, 4, 4, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
+}
+static void launch_wgrad_any(int dtype, int taps, const WgradArgs& a, unsigned grid, hipStream_t st, int64_t Cout, int64_t C0) {
+    if (taps == 9) launch_wgrad_t<9>(dtype, a, grid, st, Cout, C0);
+    else if (taps == 4) launch_wgrad_t<4>(dtype, a, grid, st, Cout, C0);
+    else launch_wgrad_t<1>(dtype, a, grid, st, Cout, C0);
 }
 
 static int check_segments(const char* who, int dtype, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
@@ -677,6 +776,7 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     a.C0 = (int)C0; a.C1 = (int)C1;
     a.nch0 = (int)(round_up(C0, kr) / kr); a.nch = a.nch0 + (int)(round_up(C1, kr) / kr);
     a.N = (int)N; a.H = (int)H; a.W = (int)W;
+    a.vin = a.vout = identity_view((int)H, (int)W);
     a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
     a.w = (const char*)w_packed; a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
     a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = (const char*)mask; a.ld_mask = ld_mask;
@@ -684,8 +784,7 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     const int bn = pick_bn(a.cout_pad);
     SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    if (taps == 9) SEGK_DISPATCH_DTYPE(dtype, T, (launch_fwd_t<T, 9>(a, bn, st)));
-    else SEGK_DISPATCH_DTYPE(dtype, T, (launch_fwd_t<T, 1>(a, bn, st)));
+    launch_fwd_any(dtype, taps, a, bn, st);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -721,36 +820,162 @@ extern "C" int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0,
     a.N = (int)N; a.H = (int)H; a.W = (int)W;
     a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
     a.dy = (const char*)dy; a.ldy = ldy; a.Cout = (int)Cout; a.ncb = (int)((Cout + kr - 1) / kr);
+    a.vdy = identity_view((int)H, (int)W);
     const int64_t ntiles = (int64_t)a.N * a.tiles_x * a.tiles_y;
     a.splits = wgrad_splits(ntiles, a.ncb, a.nch);
     a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
     a.slab = (float*)workspace;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
-    // tiling variant: skip the zero half of a 64-channel bf16 K-row when dy (or a single-K-row input) has <= 32 channels
-    const bool thin_co = dtype == SEGK_BF16 && Cout <= 32;
-    const bool thin_ci = dtype == SEGK_BF16 && !thin_co && a.nch == 1 && C0 <= 32;
-#define SEGK_WG(TAPS_)                                                                                                   \
-    do {                                                                                                                 \
-        if (dtype == SEGK_F32)                                                                                           \
-            hipLaunchKernelGGL((conv_wgrad_kernel<float, TAPS_, 2, 2, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a); \
-        else if (thin_co)                                                                                                \
-            hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS_, 2, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);  \
-        else if (thin_ci)                                                                                                \
-            hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS_, 4, 2, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);  \
-        else                                                                                                             \
-            hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS_, 4, 4, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);  \
-    } while (0)
-    if (taps == 9) SEGK_WG(9);
-    else SEGK_WG(1);
-#undef SEGK_WG
+    launch_wgrad_any(dtype, taps, a, grid, st, Cout, C0);
     SEGK_LAUNCH_CHECK();
     const int64_t total = Cout * cin_real * taps;
     int64_t rgrid = (total + kConvThreads - 1) / kConvThreads;
     if (rgrid > 8192) rgrid = 8192;
     const int seg0 = C1 ? (int)C0 : (int)cin_real;
     hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(kConvThreads), 0, st, (const float*)workspace, a.splits,
-                       (int64_t)a.ncb * kr, taps, a.nch * kr, (int)Cout, (int)cin_real, seg0, a.nch0 * kr, dw, (flags >> 1) & 1);
+                       (int64_t)a.ncb * kr, taps, a.nch * kr, (int)Cout, (int)cin_real, seg0, a.nch0 * kr, dw, (flags >> 1) & 1, 0, 0, 0,
+                       0, 0);
     SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvTranspose2d(4, stride 2, padding 1): host side
+// ------------------------------------------------------------------------------------------------
+namespace segk {
+static size_t convt_phase_bytes(int dtype, int64_t Cin, int64_t Cout, bool fwd) {
+    const int kr = krow(dtype);
+    return fwd ? (size_t)(round_up(Cin, kr) / kr * 4 * round_up(Cout, 32) * kRowBytes)
+               : (size_t)(round_up(Cout, kr) / kr * 4 * round_up(Cin, 32) * kRowBytes);
+}
+static int check_convt(const char* who, int dtype, const void* p, int64_t ld, int64_t C) {
+    if (dtype != SEGK_F32 && dtype != SEGK_BF16) return fail(SEGK_EINVAL, "%s: unknown dtype %d", who, dtype);
+    if (!p || C <= 0 || C % 8 || ld < C) return fail(SEGK_ESHAPE, "%s: channels %lld must be a positive multiple of 8 and <= ld", who, (long long)C);
+    if (!aligned16(p) || (ld * esize(dtype)) % 16) return fail(SEGK_EALIGN, "%s: pointer/ld not 16-byte aligned", who);
+    return SEGK_OK;
+}
+}  // namespace segk
+
+extern "C" size_t segk_convt_packed_bytes(int dtype, int64_t Cin, int64_t Cout) {
+    if (Cin <= 0 || Cout <= 0) return 0;
+    const size_t f = 4 * convt_phase_bytes(dtype, Cin, Cout, true), b = 4 * convt_phase_bytes(dtype, Cin, Cout, false);
+    return f > b ? f : b;
+}
+
+extern "C" int segk_convt_pack(const float* w, int64_t Cin, int64_t Cout, int dtype, void* wf, void* wb, int dev, void* stream) {
+    SEGK_REQUIRE(w && (wf || wb) && Cin > 0 && Cout > 0, SEGK_EINVAL, "convt_pack: bad arguments");
+    SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "convt_pack: unknown dtype");
+    SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "convt_pack: packed buffers must be 16-byte aligned");
+    SEGK_HIP(use_device(dev));
+    const int64_t slots = (int64_t)((wf ? 4 * convt_phase_bytes(dtype, Cin, Cout, true) : 0) + (wb ? 4 * convt_phase_bytes(dtype, Cin, Cout, false) : 0)) / 16;
+    int64_t grid = (slots + kConvThreads - 1) / kConvThreads;
+    if (grid > 4096) grid = 4096;
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((convt_pack_kernel<T>), dim3((unsigned)grid), dim3(kConvThreads), 0, (hipStream_t)stream, w,
+                                                     (int)Cin, (int)Cout, (char*)wf, (char*)wb));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_convt_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t H, int64_t W, const void* wf,
+                              int64_t Cout, const float* bias, void* y, int64_t ldy, int flags, int dev, void* stream) {
+    if (int rc = check_convt("convt_fwd(x)", dtype, x, ldx, Cin)) return rc;
+    if (int rc = check_convt("convt_fwd(y)", dtype, y, ldy, Cout)) return rc;
+    SEGK_REQUIRE(wf && aligned16(wf) && N > 0 && H > 0 && W > 0 && N * H * W * 4 < (1ll << 28), SEGK_ESHAPE, "convt_fwd: bad arguments");
+    SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "convt_fwd: bias must be 16-byte aligned");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    ConvArgs a;
+    a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
+    a.nch0 = a.nch = (int)(round_up(Cin, kr) / kr);
+    a.N = (int)N; a.H = (int)H; a.W = (int)W;
+    a.vin = identity_view((int)H, (int)W);
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
+    a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = nullptr; a.ld_mask = 0; a.relu = flags & 1; a.accumulate = 0;
+    const int bn = pick_bn(a.cout_pad);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int pa = ph >> 1, pb = ph & 1;
+        a.w = (const char*)wf + (size_t)ph * convt_phase_bytes(dtype, Cin, Cout, true);
+        a.vout = View{(int)(2 * H), (int)(2 * W), 2, 2, pa, pb};
+        for (int t = 0; t < 4; ++t) { a.tky[t] = ct_off(pa, t >> 1) + 1; a.tkx[t] = ct_off(pb, t & 1) + 1; }
+        launch_fwd_any(dtype, 4, a, bn, (hipStream_t)stream);
+        SEGK_LAUNCH_CHECK();
+    }
+    return SEGK_OK;
+}
+
+extern "C" int segk_convt_dgrad(int dtype, const void* dy, int64_t ld_dy, int64_t Cout, int64_t N, int64_t H, int64_t W, const void* wb,
+                                int64_t Cin, void* dx, int64_t ld_dx, const void* mask, int64_t ld_mask, int flags, int dev, void* stream) {
+    if (int rc = check_convt("convt_dgrad(dy)", dtype, dy, ld_dy, Cout)) return rc;
+    if (int rc = check_convt("convt_dgrad(dx)", dtype, dx, ld_dx, Cin)) return rc;
+    SEGK_REQUIRE(wb && aligned16(wb) && N > 0 && H > 0 && W > 0 && N * H * W * 4 < (1ll << 28), SEGK_ESHAPE, "convt_dgrad: bad arguments");
+    SEGK_REQUIRE(!mask || (aligned16(mask) && ld_mask >= Cin && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "convt_dgrad: mask misaligned");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    ConvArgs a;
+    a.x0 = (const char*)dy; a.x1 = nullptr; a.ld0 = ld_dy; a.ld1 = 0; a.C0 = (int)Cout; a.C1 = 0;
+    a.nch0 = a.nch = (int)(round_up(Cout, kr) / kr);
+    a.N = (int)N; a.H = (int)H; a.W = (int)W;                 // the convolution grid is the low-resolution input grid
+    a.vout = identity_view((int)H, (int)W);
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.Cout = (int)Cin; a.cout_pad = (int)round_up(Cin, 32);
+    a.bias = nullptr; a.y = (char*)dx; a.ldy = ld_dx; a.mask = (const char*)mask; a.ld_mask = ld_mask; a.relu = 0;
+    const int bn = pick_bn(a.cout_pad);
+    for (int ph = 0; ph < 4; ++ph) {
+        const int pa = ph >> 1, pb = ph & 1;
+        a.w = (const char*)wb + (size_t)ph * convt_phase_bytes(dtype, Cin, Cout, false);
+        a.vin = View{(int)(2 * H), (int)(2 * W), 2, 2, pa, pb};   // phase (a,b) of the output gradient
+        for (int t = 0; t < 4; ++t) { a.tky[t] = -ct_off(pa, t >> 1) + 1; a.tkx[t] = -ct_off(pb, t & 1) + 1; }
+        a.accumulate = (ph > 0 || ((flags >> 1) & 1)) ? 1 : 0;
+        launch_fwd_any(dtype, 4, a, bn, (hipStream_t)stream);
+        SEGK_LAUNCH_CHECK();
+    }
+    return SEGK_OK;
+}
+
+extern "C" size_t segk_convt_wgrad_workspace(int dtype, int64_t Cin, int64_t Cout, int64_t N, int64_t H, int64_t W) {
+    return segk_conv_wgrad_workspace(dtype, 4, Cin, 0, N, H, W, Cout);
+}
+
+extern "C" int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t H, int64_t W, const void* dy,
+                                int64_t ld_dy, int64_t Cout, float* dw, int flags, void* workspace, size_t workspace_bytes, int dev,
+                                void* stream) {
+    if (int rc = check_convt("convt_wgrad(x)", dtype, x, ldx, Cin)) return rc;
+    if (int rc = check_convt("convt_wgrad(dy)", dtype, dy, ld_dy, Cout)) return rc;
+    SEGK_REQUIRE(dw && workspace && N > 0 && H > 0 && W > 0 && N * H * W * 4 < (1ll << 28), SEGK_ESHAPE, "convt_wgrad: bad arguments");
+    SEGK_REQUIRE(workspace_bytes >= segk_convt_wgrad_workspace(dtype, Cin, Cout, N, H, W), SEGK_EWORKSPACE, "convt_wgrad: workspace too small");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a;
+    a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
+    a.nch0 = a.nch = (int)(round_up(Cin, kr) / kr);
+    a.N = (int)N; a.H = (int)H; a.W = (int)W;
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.dy = (const char*)dy; a.ldy = ld_dy; a.Cout = (int)Cout; a.ncb = (int)((Cout + kr - 1) / kr);
+    const int64_t ntiles = (int64_t)a.N * a.tiles_x * a.tiles_y;
+    a.splits = wgrad_splits(ntiles, a.ncb, a.nch);
+    a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
+    a.slab = (float*)workspace;
+    const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
+    const int64_t total = Cout * Cin * 4;
+    int64_t rgrid = (total + kConvThreads - 1) / kConvThreads;
+    if (rgrid > 8192) rgrid = 8192;
+    for (int ph = 0; ph < 4; ++ph) {
+        const int pa = ph >> 1, pb = ph & 1;
+        a.vdy = View{(int)(2 * H), (int)(2 * W), 2, 2, pa, pb};
+        int kidx[4];
+        for (int t = 0; t < 4; ++t) {
+            a.tky[t] = ct_off(pa, t >> 1) + 1; a.tkx[t] = ct_off(pb, t & 1) + 1;
+            kidx[t] = ct_k(pa, t >> 1) * 4 + ct_k(pb, t & 1);
+        }
+        launch_wgrad_any(dtype, 4, a, grid, st, Cout, Cin);
+        SEGK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(kConvThreads), 0, st, (const float*)workspace, a.splits,
+                           (int64_t)a.ncb * kr, 4, a.nch * kr, (int)Cout, (int)Cin, (int)Cin, a.nch0 * kr, dw, (flags >> 1) & 1, (int)Cout,
+                           kidx[0], kidx[1], kidx[2], kidx[3]);
+        SEGK_LAUNCH_CHECK();
+    }
     return SEGK_OK;
 }

@@ -488,6 +488,24 @@ __global__ __launch_bounds__(kThreads) void copy_slice_kernel(const T* __restric
     }
 }
 
+// dx = dy where the saved activation y is positive, else 0 (backward of a ReLU that follows a layer without norm)
+template <typename T>
+__global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy, const T* __restrict__ y,
+                                                            int64_t ldy, int64_t P, int C, T* __restrict__ dx, int64_t ld_dx) {
+    const int cv = C / 8;
+    const int64_t items = P * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        const int64_t p = i / cv;
+        float d[8], f[8];
+        Elem<T>::load8(dy + p * ld_dy + v * 8, d);
+        Elem<T>::load8(y + p * ldy + v * 8, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = f[j] > 0.f ? d[j] : 0.f;
+        Elem<T>::store8(dx + p * ld_dx + v * 8, d);
+    }
+}
+
 // ------------------------------------------------------------------------------ 1x1 head
 constexpr int kHeadMaxOut = 8;
 
@@ -943,6 +961,19 @@ extern "C" int segk_adam_step(float* param, const float* grad, float* exp_avg, f
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
                        lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_relu_bwd(int dtype, const void* dy, int64_t ld_dy, const void* y, int64_t ldy, int64_t P, int64_t C, void* dx,
+                             int64_t ld_dx, int dev, void* stream) {
+    SEGK_CHECK_ACT("relu_bwd(dy)", dy, ld_dy, C, dtype);
+    SEGK_CHECK_ACT("relu_bwd(y)", y, ldy, C, dtype);
+    SEGK_CHECK_ACT("relu_bwd(dx)", dx, ld_dx, C, dtype);
+    SEGK_REQUIRE(P > 0, SEGK_ESHAPE, "relu_bwd: bad shape");
+    SEGK_HIP(use_device(dev));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(grid_for(P * (C / 8))), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, P, (int)C, (T*)dx, ld_dx));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -32,6 +32,13 @@ _PROTOS = {
     "segk_conv_fwd": (I, [I, I, P, L, L, P, L, L, L, L, L, P, L, P, P, L, P, L, I, I, P]),
     "segk_conv_wgrad_workspace": (Z, [I, I, L, L, L, L, L, L]),
     "segk_conv_wgrad": (I, [I, I, P, L, L, P, L, L, L, L, L, P, L, L, L, P, I, P, Z, I, P]),
+    "segk_convt_packed_bytes": (Z, [I, L, L]),
+    "segk_convt_pack": (I, [P, L, L, I, P, P, I, P]),
+    "segk_convt_fwd": (I, [I, P, L, L, L, L, L, P, L, P, P, L, I, I, P]),
+    "segk_convt_dgrad": (I, [I, P, L, L, L, L, L, P, L, P, L, P, L, I, I, P]),
+    "segk_convt_wgrad_workspace": (Z, [I, L, L, L, L, L]),
+    "segk_convt_wgrad": (I, [I, P, L, L, L, L, L, P, L, L, P, I, P, Z, I, P]),
+    "segk_relu_bwd": (I, [I, P, L, P, L, L, L, P, L, I, P]),
     "segk_head1x1_fwd": (I, [I, P, L, L, L, L, P, P, L, P, I, P]),
     "segk_head1x1_bwd_workspace": (Z, [L, L, L, L]),
     "segk_head1x1_bwd": (I, [I, P, L, L, L, L, P, L, P, P, L, I, P, P, P, Z, I, P]),

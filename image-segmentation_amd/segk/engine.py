@@ -207,6 +207,31 @@ class Runtime:
                 m.ready = True
             c += act.C
 
+    def conv_transpose_relu(self, h, wname, bname, out=None):
+        """ConvTranspose2d(4, stride 2, padding 1) + ReLU (models/unetvgg.py:31-32,41)."""
+        w = self.p[wname]
+        Cin, Cout = w.shape[0], w.shape[1]
+        x = h.act
+        wf, wb = ops.convt_pack(w.detach(), self.dtype, want_bwd=self.need_grad)
+        u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, Cout))
+        ops.convt_fwd(x, wf, Cout, u.act, bias=self._bias(bname), relu=True)
+
+        def bwd():
+            du = self.grad_of(u.act)
+            dpre = self.new(x.N, 2 * x.H, 2 * x.W, Cout)
+            ops.relu_bwd(du, u.act, dpre)
+            dw = self.alloc_grad(wname, w)
+            ops.convt_wgrad(x, dpre, dw)
+            self._emit(wname, dw)
+            if bname is not None:
+                db = self.alloc_grad(bname, self.p[bname])
+                ops.colsum(dpre, db)
+                self._emit(bname, db)
+            ops.convt_dgrad(dpre, wb, self.grad_of(x), mask=x if h.relu_fused else None, accumulate=h.ready)
+            h.ready = True
+        self.record(bwd)
+        return u
+
     def bn_relu(self, y, prefix, out=None, eps=1e-5, momentum=0.1):
         """BatchNorm2d (+ReLU).  Training: batch statistics and running-buffer update; eval: running buffers."""
         C = y.act.C

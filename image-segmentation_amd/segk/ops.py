@@ -182,6 +182,56 @@ def conv_wgrad(x, dy, dw, taps=9, cin_real=None, accumulate=False):
     return dw
 
 
+def convt_pack(w, dtype, want_bwd=True):
+    """fp32 ConvTranspose2d weight [Cin,Cout,4,4] -> (forward phase images, data-gradient phase images)."""
+    Cin, Cout, kh, kw = w.shape
+    assert (kh, kw) == (4, 4) and w.dtype == torch.float32 and w.is_contiguous()
+    nbytes = query("segk_convt_packed_bytes", dt(dtype), Cin, Cout)
+    wf = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    wb = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if want_bwd else None
+    dev, st = _env(w)
+    call("segk_convt_pack", w.data_ptr(), Cin, Cout, dt(dtype), _p(wf), _p(wb), dev, st)
+    return wf, wb
+
+
+def convt_fwd(x, wf, Cout, out, bias=None, relu=False):
+    """out [N,2H,2W,Cout] = ConvTranspose2d(4, stride 2, padding 1)(x) (+bias, +ReLU)."""
+    assert out.C == Cout and (out.N, out.H, out.W) == (x.N, 2 * x.H, 2 * x.W) and out.dtype == x.dtype
+    dev, st = _env(x.buf)
+    with _Timed("conv_fwd"):
+        call("segk_convt_fwd", dt(x.dtype), x.ptr, x.ld, x.C, x.N, x.H, x.W, wf.data_ptr(), Cout, _p(bias), out.ptr, out.ld,
+             RELU if relu else 0, dev, st)
+    return out
+
+
+def convt_dgrad(dy, wb, dx, mask=None, accumulate=False):
+    """dx [N,H,W,Cin] from dy [N,2H,2W,Cout]; mask: forward activation whose ReLU gates dx."""
+    assert (dy.N, dy.H, dy.W) == (dx.N, 2 * dx.H, 2 * dx.W)
+    dev, st = _env(dy.buf)
+    with _Timed("conv_fwd"):
+        call("segk_convt_dgrad", dt(dy.dtype), dy.ptr, dy.ld, dy.C, dx.N, dx.H, dx.W, wb.data_ptr(), dx.C, dx.ptr, dx.ld,
+             mask.ptr if mask else None, mask.ld if mask else 0, ACCUM if accumulate else 0, dev, st)
+    return dx
+
+
+def convt_wgrad(x, dy, dw, accumulate=False):
+    """dw fp32 [Cin,Cout,4,4]."""
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == x.C * dy.C * 16
+    dev, st = _env(x.buf)
+    d = dt(x.dtype)
+    ws = workspace(query("segk_convt_wgrad_workspace", d, x.C, dy.C, x.N, x.H, x.W), x.device)
+    with _Timed("conv_wgrad"):
+        call("segk_convt_wgrad", d, x.ptr, x.ld, x.C, x.N, x.H, x.W, dy.ptr, dy.ld, dy.C, dw.data_ptr(),
+             ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
+    return dw
+
+
+def relu_bwd(dy, y, dx):
+    dev, st = _env(dy.buf)
+    call("segk_relu_bwd", dt(dy.dtype), dy.ptr, dy.ld, y.ptr, y.ld, dy.P, dy.C, dx.ptr, dx.ld, dev, st)
+    return dx
+
+
 def head_fwd(x, w, bias, logits):
     Cout = w.shape[0]
     dev, st = _env(x.buf)

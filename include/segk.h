@@ -146,6 +146,26 @@ int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0
                     int64_t cin_real, float* dw, int flags, void* workspace, size_t workspace_bytes, int dev,
                     void* stream);
 
+/* ConvTranspose2d(kernel 4, stride 2, padding 1): [N,H,W,Cin] -> [N,2H,2W,Cout], run as four phase convolutions
+ * (2x2 taps each) on the same MFMA kernels.  w is the module's fp32 [Cin,Cout,4,4] weight.
+ * replaces: nn.ConvTranspose2d(mid, out, kernel_size=4, stride=2, padding=1) forward/backward of the
+ *           `if_convtrans=True` decoder tail (models/unetvgg.py:31-32).
+ * segk_convt_pack writes the per-phase forward images into wf and data-gradient images into wb (either may be
+ * NULL; each buffer segk_convt_packed_bytes large).  fwd flags bit0: ReLU epilogue.  dgrad: dx (H x W, Cin) from
+ * dy (2H x 2W, Cout), optional ReLU-backward mask of the producer of x, flags bit1: accumulate.  wgrad: dw in the
+ * module's [Cin,Cout,4,4] layout, flags bit1: accumulate.                                                  */
+size_t segk_convt_packed_bytes(int dtype, int64_t Cin, int64_t Cout);
+int segk_convt_pack(const float* w, int64_t Cin, int64_t Cout, int dtype, void* wf, void* wb, int dev, void* stream);
+int segk_convt_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t H, int64_t W, const void* wf,
+                   int64_t Cout, const float* bias, void* y, int64_t ldy, int flags, int dev, void* stream);
+int segk_convt_dgrad(int dtype, const void* dy, int64_t ld_dy, int64_t Cout, int64_t N, int64_t H, int64_t W,
+                     const void* wb, int64_t Cin, void* dx, int64_t ld_dx, const void* mask, int64_t ld_mask, int flags,
+                     int dev, void* stream);
+size_t segk_convt_wgrad_workspace(int dtype, int64_t Cin, int64_t Cout, int64_t N, int64_t H, int64_t W);
+int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t H, int64_t W, const void* dy,
+                     int64_t ld_dy, int64_t Cout, float* dw, int flags, void* workspace, size_t workspace_bytes, int dev,
+                     void* stream);
+
 /* 1x1 head: logits[n,co,y,x] (NCHW fp32) = bias[co] + sum_ci x[n,y,x,ci]*w[co,ci].
  * replaces: models/unetvgg.py:88,105 (final = Conv2d(32,C,1)); models/unetplusplus.py:58,81.      */
 int segk_head1x1_fwd(int dtype, const void* x, int64_t ld, int64_t Cin, int64_t N, int64_t HW, const float* w,
@@ -213,6 +233,11 @@ int segk_upsample2x_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_
 int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, const void* y, int64_t ldy, int64_t N,
                         int64_t H, int64_t W, int64_t C, int flags, void* dx, int64_t ld_dx, int dev,
                         void* stream);
+
+/* dx = dy where y > 0 else 0 over a [P,C] slice: backward of a ReLU whose producer has no norm to fuse it into
+ * (the ReLU behind the transposed convolution, models/unetvgg.py:41).                              */
+int segk_relu_bwd(int dtype, const void* dy, int64_t ld_dy, const void* y, int64_t ldy, int64_t P, int64_t C, void* dx,
+                  int64_t ld_dx, int dev, void* stream);
 
 /* out[c] = sum over pixels of x[p,c] (fp32, deterministic two-stage); flags bit1: out += .
  * replaces: bias gradient of Conv2d/ConvTranspose2d backward.                                      */

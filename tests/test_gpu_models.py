@@ -48,7 +48,7 @@ def run_step(name, dtype, side=64, n=2, tag=None):
     return model, logits.detach(), loss.detach()
 
 
-MODELS = ["unetvgg_c4", "unetvgg_c3", "unetvgginout_c4"]
+MODELS = ["unetvgg_c4", "unetvgg_c3", "unetvgginout_c4", "nestedunet_c4", "unetvgg_c4_convtrans"]
 
 
 def oracle_step(name, dtype, side=64, n=2, tag=None, autocast=False):

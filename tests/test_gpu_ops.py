@@ -106,6 +106,41 @@ def test_conv_two_segments(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 12, 20, 64, 32), (1, 24, 24, 128, 64), (2, 6, 6, 256, 256)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_transpose_4s2p1(dtype, case):
+    """nn.ConvTranspose2d(kernel 4, stride 2, padding 1) forward / data gradient / weight gradient."""
+    from segk import ops
+    N, H, W, Cin, Cout = case
+    x = rnd((N, Cin, H, W), dtype, 21)
+    w = rnd((Cin, Cout, 4, 4), dtype, 22, scale=(2.0 / (4 * Cin)) ** 0.5)
+    b = rnd((Cout,), torch.float32, 23)
+    dy = rnd((N, Cout, 2 * H, 2 * W), dtype, 24)
+    xa = to_act(x, dtype, ld=Cin + 8, c0=8)
+    wf, wb = ops.convt_pack(w.cuda(), dtype)
+    out = ops.Act(torch.full((N, 2 * H, 2 * W, Cout + 16), 7.0, dtype=dtype, device="cuda"), 0, Cout)
+    ops.convt_fwd(xa, wf, Cout, out, bias=b.cuda(), relu=True)
+    ref = F.relu(F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2, padding=1)).float()
+    report("convt_fwd", from_act(out), ref, **TOL[dtype])
+    assert float(out.buf[..., Cout:].float().min()) == 7.0, "wrote outside the output slice"
+    dya = to_act(dy, dtype, ld=Cout + 8)
+    mask = rnd((N, Cin, H, W), dtype, 25)
+    dx = ops.Act.empty(N, H, W, Cin, dtype, "cuda")
+    ops.convt_dgrad(dya, wb, dx, mask=to_act(mask, dtype))
+    ref_dx = F.conv2d(dy.double(), w.double(), stride=2, padding=1).float() * (mask > 0)
+    report("convt_dgrad", from_act(dx), ref_dx, **TOL[dtype])
+    ops.convt_dgrad(dya, wb, dx, mask=to_act(mask, dtype), accumulate=True)
+    t2 = dict(TOL[dtype]); t2["atol"] *= 2
+    report("convt_dgrad_accum", from_act(dx), 2 * ref_dx, **t2)
+    dw = torch.empty(Cin, Cout, 4, 4, device="cuda")
+    ops.convt_wgrad(xa, dya, dw)
+    xr = x.double()
+    wr = w.double().requires_grad_(True)
+    F.conv_transpose2d(xr, wr, stride=2, padding=1).backward(dy.double())
+    ref_dw = wr.grad.float()
+    report("convt_wgrad", dw.cpu(), ref_dw, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * max(float(ref_dw.abs().max()), 1.0) * 0.05)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_first_conv_im2col(dtype):
     from segk import ops
     N, H, W, Cin, Cout = 2, 24, 32, 3, 64
