@@ -76,7 +76,7 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(const T* __rest
     float s[8], q[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
-    for (int64_t p = lo + r; p < hi; p += rows) {
+    for (int64_t p = lo + r; p < hi && r < rows; p += rows) {   // r >= rows: spare threads when C/8 does not divide the block
         float a[8];
         Elem<T>::load8(base + p * ld, a);
 #pragma unroll
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restric
     }
     const T* xb = x + (int64_t)g * M * ldx + v * 8;
     T* yb = y + (int64_t)g * M * ldy + v * 8;
-    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M; p += (int64_t)gridDim.x * rows) {
+    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M && r < rows; p += (int64_t)gridDim.x * rows) {
         float a[8];
         Elem<T>::load8(xb + p * ldx, a);
 #pragma unroll
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __r
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    for (int64_t p = lo + r; p < hi; p += rows) {
+    for (int64_t p = lo + r; p < hi && r < rows; p += rows) {   // r >= rows: spare threads when C/8 does not divide the block
         float a[8], d[8];
         Elem<T>::load8(xb + p * ldx, a);
         Elem<T>::load8(db + p * ld_dy, d);
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
     const T* xb = x + (int64_t)g * M * ldx + v * 8;
     const T* db = dy + (int64_t)g * M * ld_dy + v * 8;
     T* ob = dx + (int64_t)g * M * ld_dx + v * 8;
-    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M; p += (int64_t)gridDim.x * rows) {
+    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M && r < rows; p += (int64_t)gridDim.x * rows) {
         float a[8], d[8];
         Elem<T>::load8(xb + p * ldx, a);
         Elem<T>::load8(db + p * ld_dy, d);
@@ -673,7 +673,7 @@ static int check_act(const char* who, const void* p, int64_t ld, int64_t C, int 
     } while (0)
 
 static int check_norm_c(const char* who, int64_t C) {
-    if (C % 8 != 0 || !is_pow2(C / 8) || C / 8 > kThreads) return fail(SEGK_ESHAPE, "%s: C/8 must be a power of two <= 256 (C=%lld)", who, (long long)C);
+    if (C % 8 != 0 || C <= 0 || C / 8 > kThreads) return fail(SEGK_ESHAPE, "%s: C must be a multiple of 8, at most 2048 (C=%lld)", who, (long long)C);
     return SEGK_OK;
 }
 

@@ -224,3 +224,50 @@ def test_bench_shape_properties():
         full = model(x)
         part = model(x[2:4])
     assert torch.equal(full[2:4], part)
+
+
+BLOCKS = [
+    ("decoder_bilinear", dict(if_convtrans=False), (2, 64, 16, 24)),
+    ("decoder_convtrans", dict(if_convtrans=True), (2, 64, 16, 24)),
+    ("decoder_noupsam", dict(noupsam=True), (2, 64, 16, 24)),
+    ("double_conv", None, (2, 32, 24, 16)),
+]
+
+
+@pytest.mark.parametrize("kind,kw,shape", BLOCKS, ids=[b[0] for b in BLOCKS])
+def test_standalone_blocks(kind, kw, shape):
+    """make_decoder_block / conv_block_nested used on their own on CUDA tensors (models/unetvgg.py:6-41,
+    models/unetplusplus.py:6-24): output, input gradient and parameter gradients against the oracle block."""
+    from oracle import ref_models as RM
+    from segk import _lib
+    N, C, H, W = shape
+    if kw is None:
+        from models.unetplusplus import conv_block_nested
+        blk, ref = conv_block_nested(C, 48, 40), RM.RefDoubleConv(C, 48, 40)
+    else:
+        from models.unetvgg import make_decoder_block
+        blk, ref = make_decoder_block(C, 48, 40, **kw), RM.decoder_block(C, 48, 40, **kw)
+    RM.hash_init_(blk), RM.hash_init_(ref)
+    ref = ref.double().train()
+    blk = blk.cuda().train()
+    x = RM.hash_uniform(f"block:{kind}:x", shape)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    dy = RM.hash_uniform(f"block:{kind}:dy", tuple(yr.shape))
+    yr.backward(dy.double())
+    xg = x.cuda().requires_grad_(True)
+    before = _lib.launches
+    y = blk(xg)
+    y.backward(dy.cuda())
+    assert _lib.launches - before >= 6
+    report(f"{kind}/out", y.detach().cpu(), yr.detach().float(), rtol=1e-4, atol=1e-4)
+    assert rel_l2(xg.grad.cpu(), xr.grad.float()) < 1e-4
+    for (k, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        scale = float(q.grad.norm())
+        if scale < 1e-9:
+            assert float(p.grad.norm()) < 1e-5, k
+        else:
+            assert float((p.grad.double().cpu() - q.grad).norm()) / scale < 1e-4, k
+    # the CPU path of the same module is plain torch.nn
+    yc = blk.cpu()(x)
+    report(f"{kind}/host_out", yc.detach(), yr.detach().float(), rtol=1e-4, atol=1e-5)

@@ -164,7 +164,7 @@ def test_first_conv_im2col(dtype):
 
 # ---------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape", [(4, 64, 24, 24), (2, 256, 8, 16), (3, 32, 48, 48)], ids=str)
+@pytest.mark.parametrize("shape", [(4, 64, 24, 24), (2, 256, 8, 16), (3, 32, 48, 48), (2, 40, 12, 20)], ids=str)
 def test_batchnorm_relu_fwd_bwd(dtype, shape):
     from segk import ops
     N, C, H, W = shape
