@@ -468,8 +468,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 #pragma unroll
     for (int k = 0; k < XL; ++k) {
         const int q = k * kConvThreads + tid;
-        const int pix = q >> 3, sl = (q & 7) ^ wg_swz<T>(pix);
+        const int pix = q >> 3;
         const int hy = pix / HW_, hx = pix - hy * HW_;
+        const int sl = (q & 7) ^ wg_swz<T>(hx);   // halo swizzle by column (== by pixel parity for fp32)
         xinfo[k] = (q < HPIX * 8 && xch + sl * EPS < xcmax) ? ((hy << 16) | (hx << 8) | (sl * EPS)) : -1;
     }
 #pragma unroll
@@ -508,6 +509,35 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         }
     };
 
+    // bf16 operand reads (transposing 8-byte LDS reads): lane (li = lane&15, g) with q = li>>2, p = li&3 supplies the
+    // address of pixel (row g>>1, column 8*(g&1) + q (+4 for the second half)) of a 32-pixel K-step and of 8-byte unit
+    // (tile*4 + p); it receives channel tile*16 + li.  LDS byte addresses for stage 0: the output-gradient tile, and
+    // the input halo per column variant (kx for 3x3 taps; the whole tap for the 2x2 phase taps, whose offsets are
+    // run-time values); the halo swizzle depends on the halo COLUMN only, so taps that differ in ky and successive
+    // K-steps reuse the same register with another immediate offset.
+    constexpr int NV = TAPS == 9 ? 3 : (TAPS == 4 ? 4 : 1);
+    unsigned adrA[WTI][2], adrB[NV][WTJ][2];
+    if constexpr (kBf16) {
+        const int q = l15 >> 2, p = l15 & 3, prow = g >> 1, pcol = 8 * (g & 1) + q;
+#pragma unroll
+        for (int i = 0; i < WTI; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int pix = prow * kTW + pcol + 4 * h, u = (wi * WTI + i) * 4 + p;
+                adrA[i][h] = lds0 + XBYTES + pix * kRowBytes + (((u >> 1) ^ wg_swz<T>(pix)) << 4) + (u & 1) * 8;
+            }
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int j = 0; j < WTJ; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int kx = TAPS == 9 ? v : (TAPS == 4 ? a.tkx[v] : 0), kyr = TAPS == 4 ? a.tky[v] : 0;
+                    const int hx = pcol + 4 * h + kx, hp = (prow + kyr) * HW_ + hx, u = (wj * WTJ + j) * 4 + p;
+                    adrB[v][j][h] = lds0 + hp * kRowBytes + (((u >> 1) ^ wg_swz<T>(hx)) << 4) + (u & 1) * 8;
+                }
+    }
+
     if (t_lo < t_hi) stage(t_lo, 0);
     dma_wait_all();
     __syncthreads();
@@ -520,39 +550,30 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         const char* s_dy = s_x + XBYTES;
 
         if constexpr (kBf16) {
-            // K-step = 32 pixels = two tile rows.  Lane (li = lane&15, g): q = li>>2, p = li&3 supplies the
-            // address of pixel row 8g+q (+4), 8-byte unit (tile*4 + p); it receives channel tile*16+li.
-            const int q = l15 >> 2, p = l15 & 3;
+            // K-step = 32 pixels = two tile rows; every address is a per-lane base (advanced with the stage) plus a
+            // compile-time offset, so the loop issues no address arithmetic between the MFMAs.
+            typedef __attribute__((address_space(3))) char* lds_cptr;
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 #pragma unroll 1
             for (int kk = 0; kk < TPIX / 32; ++kk) {
                 s16x8 fa[WTI];
-                int kpix[2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) kpix[h] = kk * 32 + 8 * g + q + 4 * h;
-#pragma unroll
-                for (int i = 0; i < WTI; ++i) {
-                    const int u = (wi * WTI + i) * 4 + p;
+                for (int i = 0; i < WTI; ++i)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        const int pix = kpix[h];
-                        const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                            (lds_s16x4)(&s_dy[pix * kRowBytes + (((u >> 1) ^ wg_swz<T>(pix)) << 4) + (u & 1) * 8]));
+                        const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((lds_cptr)(size_t)adrA[i][h]));
                         fa[i][4 * h + 0] = r[0]; fa[i][4 * h + 1] = r[1]; fa[i][4 * h + 2] = r[2]; fa[i][4 * h + 3] = r[3];
                     }
-                }
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
-                    const int ky = TAPS == 9 ? t / 3 : (TAPS == 4 ? a.tky[t] : 0), kx = TAPS == 9 ? t % 3 : (TAPS == 4 ? a.tkx[t] : 0);
+                    const int v = TAPS == 9 ? t % 3 : (TAPS == 4 ? t : 0), ky = TAPS == 9 ? t / 3 : 0;
 #pragma unroll
                     for (int j = 0; j < WTJ; ++j) {
-                        const int u = (wj * WTJ + j) * 4 + p;
                         s16x8 fb;
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            const int hp = ((kpix[h] >> 4) + ky) * HW_ + (kpix[h] & 15) + kx;
                             const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (lds_s16x4)(&s_x[hp * kRowBytes + (((u >> 1) ^ wg_swz<T>(hp)) << 4) + (u & 1) * 8]));
+                                (lds_s16x4)((lds_cptr)(size_t)adrB[v][j][h] + ky * HW_ * kRowBytes));
                             fb[4 * h + 0] = r[0]; fb[4 * h + 1] = r[1]; fb[4 * h + 2] = r[2]; fb[4 * h + 3] = r[3];
                         }
 #pragma unroll
@@ -561,6 +582,21 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                                                                                   __builtin_bit_cast(bf16x8, fb), acc[t][i][j], 0, 0, 0);
                     }
                 }
+                // advance to the next K-step: two tile rows; after the last one, to the start of the other stage
+                const bool last = kk == TPIX / 32 - 1;
+                const int back = st == 0 ? (XBYTES + DBYTES) : -(XBYTES + DBYTES);
+                const int stepA = last ? back - (TPIX / 32 - 1) * 32 * kRowBytes : 32 * kRowBytes;
+                const int stepB = last ? back - (TPIX / 32 - 1) * 2 * HW_ * kRowBytes : 2 * HW_ * kRowBytes;
+#pragma unroll
+                for (int i = 0; i < WTI; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) adrA[i][h] += stepA;
+#pragma unroll
+                for (int v = 0; v < NV; ++v)
+#pragma unroll
+                    for (int j = 0; j < WTJ; ++j)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) adrB[v][j][h] += stepB;
             }
         } else {
             // fp32: K-step = 4 pixels; lane (m = lane&15, k = lane>>4) reads one element of each operand.
@@ -576,11 +612,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
                     const int ky = TAPS == 9 ? t / 3 : (TAPS == 4 ? a.tky[t] : 0), kx = TAPS == 9 ? t % 3 : (TAPS == 4 ? a.tkx[t] : 0);
-                    const int hp = ((pix >> 4) + ky) * HW_ + (pix & 15) + kx;
+                    const int hx = (pix & 15) + kx, hp = ((pix >> 4) + ky) * HW_ + hx;
 #pragma unroll
                     for (int j = 0; j < WTJ; ++j) {
                         const int c = (wj * WTJ + j) * 16 + l15;
-                        const float fb = *reinterpret_cast<const float*>(&s_x[hp * kRowBytes + ((((c >> 2) ^ wg_swz<T>(hp)) << 4) | ((c & 3) << 2))]);
+                        const float fb = *reinterpret_cast<const float*>(&s_x[hp * kRowBytes + ((((c >> 2) ^ wg_swz<T>(hx)) << 4) | ((c & 3) << 2))]);
 #pragma unroll
                         for (int i = 0; i < WTI; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb, acc[t][i][j], 0, 0, 0);
                     }

@@ -13,6 +13,9 @@ LAYERS = [("conv1.3", 384, 64, 64), ("conv2.7", 192, 64, 128), ("conv2.10", 192,
           ("center.0", 12, 512, 512), ("center.2", 12, 512, 256), ("dec5.0", 24, 768, 512), ("dec5.2", 24, 512, 256),
           ("dec4.0", 48, 768, 512), ("dec4.2", 48, 512, 256), ("dec3.0", 96, 512, 256), ("dec3.2", 96, 256, 64),
           ("dec2.0", 192, 192, 128), ("dec2.2", 192, 128, 32), ("dec1.0", 384, 96, 32)]
+only = os.environ.get("ONLY")
+if only:
+    LAYERS = [l for l in LAYERS if l[0] in only.split(",")]
 which = sys.argv[1:] or ["fwd", "dgrad", "wgrad"]
 tot = {k: 0.0 for k in which}
 totf = 0.0
