@@ -47,7 +47,7 @@ struct ConvArgs {
     int Cout, cout_pad;
     const float* bias;
     char* y; int64_t ldy;
-    const char* mask; int64_t ld_mask;
+    const char* mask; int64_t ld_mask; int mask_c;   // output channels below mask_c are zeroed where mask <= 0
     int relu, accumulate;
 };
 
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (a.mask) {
+            if (a.mask && co < a.mask_c) {
                 float m[4];
                 Elem<T>::load4(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
 #pragma unroll
@@ -796,7 +796,7 @@ extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, in
 
 extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1, int64_t C1,
                              int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout, const float* bias, void* y,
-                             int64_t ldy, const void* mask, int64_t ld_mask, int flags, int dev, void* stream) {
+                             int64_t ldy, const void* mask, int64_t ld_mask, int64_t mask_channels, int flags, int dev, void* stream) {
     if (int rc = check_segments("conv_fwd", dtype, x0, ld0, C0, x1, ld1, C1)) return rc;
     SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_fwd: taps must be 1 or 9");
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_fwd: bad N/H/W");
@@ -804,7 +804,9 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     SEGK_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldy >= Cout, SEGK_ESHAPE, "conv_fwd: Cout %lld must be a multiple of 4 and <= ldy", (long long)Cout);
     SEGK_REQUIRE(aligned16(y) && (ldy * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_fwd: output pointer/ld misaligned");
     SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "conv_fwd: bias must be 16-byte aligned");
-    SEGK_REQUIRE(!mask || (aligned16(mask) && ld_mask >= Cout && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "conv_fwd: mask misaligned");
+    SEGK_REQUIRE(!mask || (aligned16(mask) && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "conv_fwd: mask misaligned");
+    SEGK_REQUIRE(!mask || (mask_channels > 0 && mask_channels <= Cout && mask_channels % 4 == 0 && ld_mask >= mask_channels), SEGK_ESHAPE,
+                 "conv_fwd: mask_channels must be a multiple of 4 in (0, Cout] and fit ld_mask");
     SEGK_HIP(use_device(dev));
     const int kr = krow(dtype);
     ConvArgs a;
@@ -815,7 +817,7 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     a.vin = a.vout = identity_view((int)H, (int)W);
     a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
     a.w = (const char*)w_packed; a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
-    a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = (const char*)mask; a.ld_mask = ld_mask;
+    a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = (const char*)mask; a.ld_mask = ld_mask; a.mask_c = (int)mask_channels;
     a.relu = flags & 1; a.accumulate = (flags >> 1) & 1;
     const int bn = pick_bn(a.cout_pad);
     SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv_fwd: grid too large");
@@ -928,7 +930,7 @@ extern "C" int segk_convt_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin
     a.vin = identity_view((int)H, (int)W);
     a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
     a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
-    a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = nullptr; a.ld_mask = 0; a.relu = flags & 1; a.accumulate = 0;
+    a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = nullptr; a.ld_mask = 0; a.mask_c = 0; a.relu = flags & 1; a.accumulate = 0;
     const int bn = pick_bn(a.cout_pad);
     for (int ph = 0; ph < 4; ++ph) {
         const int pa = ph >> 1, pb = ph & 1;
@@ -956,7 +958,7 @@ extern "C" int segk_convt_dgrad(int dtype, const void* dy, int64_t ld_dy, int64_
     a.vout = identity_view((int)H, (int)W);
     a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
     a.Cout = (int)Cin; a.cout_pad = (int)round_up(Cin, 32);
-    a.bias = nullptr; a.y = (char*)dx; a.ldy = ld_dx; a.mask = (const char*)mask; a.ld_mask = ld_mask; a.relu = 0;
+    a.bias = nullptr; a.y = (char*)dx; a.ldy = ld_dx; a.mask = (const char*)mask; a.ld_mask = ld_mask; a.mask_c = (int)Cin; a.relu = 0;
     const int bn = pick_bn(a.cout_pad);
     for (int ph = 0; ph < 4; ++ph) {
         const int pa = ph >> 1, pb = ph & 1;

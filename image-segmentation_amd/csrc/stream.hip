@@ -467,6 +467,122 @@ __global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const T* __restr
     }
 }
 
+// Work decomposition of the resampling kernels: a block owns a TY x 8 patch of LOW-resolution pixels times a group of
+// CG channel vectors (TY*8*CG = 256 threads), so that the overlapping neighbourhoods of adjacent pixels are served
+// by the block's own L1 instead of being fetched once per XCD (consecutive blocks run on different XCDs, whose L2s
+// do not share lines).
+struct PatchItem { int64_t n; int h, w, v; bool ok; };
+__host__ __device__ inline int patch_cg(int cv) { return cv % 8 == 0 ? 8 : (cv % 4 == 0 ? 4 : (cv % 2 == 0 ? 2 : 1)); }
+static inline int64_t patch_blocks(int64_t N, int64_t H, int64_t W, int64_t C) {
+    const int cv = (int)(C / 8), cg = patch_cg(cv), ty = kThreads / (8 * cg);
+    return N * ((H + ty - 1) / ty) * ((W + 7) / 8) * (cv / cg);
+}
+__device__ __forceinline__ PatchItem patch_item(int64_t block, int tid, int H, int W, int cv) {
+    const int cg = patch_cg(cv), ty = kThreads / (8 * cg);
+    const int ncg = cv / cg, tiles_x = (W + 7) / 8, tiles_y = (H + ty - 1) / ty;
+    const int cgi = (int)(block % ncg); block /= ncg;
+    const int tx = (int)(block % tiles_x); block /= tiles_x;
+    const int tyi = (int)(block % tiles_y);
+    PatchItem it;
+    it.n = block / tiles_y;
+    it.v = cgi * cg + tid % cg;
+    it.w = tx * 8 + (tid / cg) % 8;
+    it.h = tyi * ty + tid / (cg * 8);
+    it.ok = it.h < H && it.w < W;
+    return it;
+}
+
+// Fast paths for align_corners=False (the decoder blocks): with scale 2 the taps are fixed.  Output rows 2h and
+// 2h+1 read input rows (h-1, h) and (h, h+1) with weights (0.25, 0.75) and (0.75, 0.25); output 0 puts all its
+// weight on input 0, and past the last row the clamped neighbour is the row itself.  One thread owns one INPUT
+// pixel (8 channels).
+//
+// forward: 3x3 input neighbourhood -> the 2x2 output block, same expression per output as the generic kernel
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_fwd_half_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
+                                                                     const float* __restrict__ stats, int relu,
+                                                                     T* __restrict__ y, int64_t ldy) {
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, H, W, cv);
+    if (!it.ok) return;
+    const int h = it.h, w = it.w, v = it.v;
+    const int64_t n = it.n;
+    const int hs[3] = {h > 0 ? h - 1 : 0, h, h < H - 1 ? h + 1 : h};
+    const int ws[3] = {w > 0 ? w - 1 : 0, w, w < W - 1 ? w + 1 : w};
+    const T* b = x + n * H * W * ldx + v * 8;
+    float a[3][3][8];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Elem<T>::load8(b + ((int64_t)hs[r] * W + ws[c]) * ldx, a[r][c]);
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        mean[j] = stats ? stats[(n * C + c) * 2] : 0.f;
+        rstd[j] = stats ? stats[(n * C + c) * 2 + 1] : 1.f;
+    }
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            // taps (dy, dy+1) x (dx, dx+1) of the neighbourhood; weight of the second tap
+            const float wy1 = dy == 0 ? (h > 0 ? 0.75f : 0.f) : 0.25f, wy0 = 1.f - wy1;
+            const float wx1 = dx == 0 ? (w > 0 ? 0.75f : 0.f) : 0.25f, wx0 = 1.f - wx1;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float val = wy0 * (wx0 * a[dy][dx][j] + wx1 * a[dy][dx + 1][j]) + wy1 * (wx0 * a[dy + 1][dx][j] + wx1 * a[dy + 1][dx + 1][j]);
+                if (stats) val = (val - mean[j]) * rstd[j];
+                o[j] = relu ? fmaxf(val, 0.f) : val;
+            }
+            Elem<T>::store8(y + ((n * Ho + 2 * h + dy) * Wo + 2 * w + dx) * ldy + v * 8, o);
+        }
+}
+
+// backward: the 4x4 output neighbourhood [2h-1, 2h+2] x [2w-1, 2w+2] with separable weights
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_bwd_half_kernel(const T* __restrict__ dy, int64_t ld_dy,
+                                                                     const T* __restrict__ y, int64_t ldy, int H, int W, int C,
+                                                                     int relu, T* __restrict__ dx, int64_t ld_dx) {
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, H, W, cv);
+    if (!it.ok) return;
+    const int h = it.h, w = it.w, v = it.v;
+    const int64_t n = it.n;
+    const float wy[4] = {h > 0 ? 0.25f : 0.f, h > 0 ? 0.75f : 1.f, h < H - 1 ? 0.75f : 1.f, h < H - 1 ? 0.25f : 0.f};
+    const float wx[4] = {w > 0 ? 0.25f : 0.f, w > 0 ? 0.75f : 1.f, w < W - 1 ? 0.75f : 1.f, w < W - 1 ? 0.25f : 0.f};
+    const int oy[4] = {h > 0 ? 2 * h - 1 : 0, 2 * h, 2 * h + 1, h < H - 1 ? 2 * h + 2 : 2 * h + 1};
+    const int ox[4] = {w > 0 ? 2 * w - 1 : 0, 2 * w, 2 * w + 1, w < W - 1 ? 2 * w + 2 : 2 * w + 1};
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+        // separable: weighted sum along the row first, then one multiply-add per row
+        float row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 4; ++kx) {
+            const int64_t op = (n * Ho + oy[ky]) * Wo + ox[kx];
+            float d[8];
+            Elem<T>::load8(dy + op * ld_dy + v * 8, d);
+            if (relu) {
+                float f[8];
+                Elem<T>::load8(y + op * ldy + v * 8, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = f[j] > 0.f ? d[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) row[j] += wx[kx] * d[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy[ky] * row[j];
+    }
+    Elem<T>::store8(dx + ((n * H + h) * W + w) * ld_dx + v * 8, acc);
+}
+
 // ------------------------------------------------------------------------------ slices
 template <typename T>
 __global__ __launch_bounds__(kThreads) void copy_slice_kernel(const T* __restrict__ src, int64_t ld_src, T* __restrict__ dst,
@@ -836,6 +952,13 @@ extern "C" int segk_upsample2x_fwd(int dtype, const void* x, int64_t ldx, int64_
     SEGK_CHECK_ACT("upsample_fwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0, SEGK_ESHAPE, "upsample_fwd: bad shape");
     SEGK_HIP(use_device(dev));
+    if (!((flags >> 2) & 1)) {
+        SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_half_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads),
+                                                         0, (hipStream_t)stream, (const T*)x, ldx, (int)H, (int)W, (int)C, stats,
+                                                         flags & 1, (T*)y, ldy));
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     const int64_t items = N * 4 * H * W * (C / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
                                                      (const T*)x, ldx, N, (int)H, (int)W, (int)C, stats, flags & 1, (flags >> 2) & 1,
@@ -852,6 +975,13 @@ extern "C" int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, con
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0, SEGK_ESHAPE, "upsample_bwd: bad shape");
     SEGK_HIP(use_device(dev));
     const int64_t items = N * H * W * (C / 8);
+    if (!((flags >> 2) & 1)) {
+        SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_half_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
+                                                         (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, (int)H, (int)W,
+                                                         (int)C, flags & 1, (T*)dx, ld_dx));
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
                                                      (const T*)dy, ld_dy, (const T*)y, ldy, N, (int)H, (int)W, (int)C, flags & 1,
                                                      (flags >> 2) & 1, (T*)dx, ld_dx));

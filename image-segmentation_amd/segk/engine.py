@@ -180,11 +180,15 @@ class Runtime:
     def _dgrad(self, segs, dy, wb, Cin):
         """Data gradient of a convolution into the gradient slices of its input segments."""
         def mask_of(members):
-            fused = [m for m in members if m.relu_fused]
-            if not fused:
+            """Act covering the leading members whose ReLU backward is left to this consumer (or None)."""
+            k = 0
+            while k < len(members) and members[k].relu_fused:
+                k += 1
+            assert not any(m.relu_fused for m in members[k:]), "fused-ReLU tensors must lead their concat segment"
+            if k == 0:
                 return None
-            assert len(members) == 1, "a fused-ReLU tensor must be a whole segment"
-            return members[0].act
+            a = members[0].act
+            return Act(a.buf, a.c0, sum(m.act.C for m in members[:k]))
 
         def state(members):
             r = [m.ready for m in members]
@@ -213,13 +217,11 @@ class Runtime:
         Cin, Cout = w.shape[0], w.shape[1]
         x = h.act
         wf, wb = ops.convt_pack(w.detach(), self.dtype, want_bwd=self.need_grad)
-        u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, Cout))
+        u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, Cout), relu_fused=True)   # consumer applies the ReLU backward
         ops.convt_fwd(x, wf, Cout, u.act, bias=self._bias(bname), relu=True)
 
         def bwd():
-            du = self.grad_of(u.act)
-            dpre = self.new(x.N, 2 * x.H, 2 * x.W, Cout)
-            ops.relu_bwd(du, u.act, dpre)
+            dpre = self.grad_of(u.act)
             dw = self.alloc_grad(wname, w)
             ops.convt_wgrad(x, dpre, dw)
             self._emit(wname, dw)
@@ -258,6 +260,7 @@ class Runtime:
         return a
 
     def pool(self, a, out=None):
+        assert not a.relu_fused, "max pool cannot consume a tensor whose ReLU backward is deferred"
         x = a.act
         p = Var(out or self.new(x.N, x.H // 2, x.W // 2, x.C))
         ops.maxpool_fwd(x, p.act)
@@ -274,7 +277,8 @@ class Runtime:
         stats = torch.empty(2 * x.N * x.C, dtype=torch.float32, device=self.device)
         ops.norm_stats(x, x.N, eps, stats)
         if upsample:
-            u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C))
+            # u = relu(...): the ReLU backward is applied by the consumer's data gradient (relu_fused)
+            u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C), relu_fused=True)
             ops.upsample_fwd(x, u.act, stats=stats, relu=True, align=False)
         else:
             u = Var(out or self.new(x.N, x.H, x.W, x.C))
@@ -285,7 +289,7 @@ class Runtime:
             dy = self.grad_of(x)
             if upsample:
                 dxh = self.new(x.N, x.H, x.W, x.C)
-                ops.upsample_bwd(du, u.act, dxh, relu=True, align=False)
+                ops.upsample_bwd(du, None, dxh, relu=False, align=False)
                 ops.norm_bwd(dxh, x, x.N, stats, None, None, False, dy)
             else:
                 ops.norm_bwd(du, x, x.N, stats, None, None, True, dy)
@@ -295,6 +299,7 @@ class Runtime:
 
     def up(self, a, out=None, align=True):
         """Plain bilinear x2 (models/unetplusplus.py:36)."""
+        assert not a.relu_fused, "up-sampling cannot consume a tensor whose ReLU backward is deferred"
         x = a.act
         u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C))
         ops.upsample_fwd(x, u.act, stats=None, relu=False, align=align)

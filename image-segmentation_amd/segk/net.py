@@ -10,7 +10,7 @@ import os
 import torch
 from torch import nn
 
-from . import _lib
+from . import _lib, ops
 from .engine import Runtime
 
 _DEFAULT_DTYPE = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[
@@ -100,7 +100,10 @@ class _BlockFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         rt = ctx.rt
-        rt.grad_of(ctx.out.act).nchw().copy_(dout)
+        g = rt.grad_of(ctx.out.act)
+        g.nchw().copy_(dout)
+        if ctx.out.relu_fused:     # nobody downstream applies the output ReLU's backward: do it here
+            ops.relu_bwd(g, ctx.out.act, g)
         rt.backward_keep()
         dx = rt.grad_of(ctx.v.act).nchw().float().contiguous() if (ctx.needs_input_grad[1] and ctx.v.ready) else None
         rt.release()

@@ -153,7 +153,8 @@ def _segs(x):
 
 
 def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, accumulate=False):
-    """out = conv(x) with the packed image `w_packed`; x is an Act or a pair of Acts (channel concat)."""
+    """out = conv(x) with the packed image `w_packed`; x is an Act or a pair of Acts (channel concat).
+    mask: Act over the first mask.C output channels; those are zeroed where mask <= 0."""
     a, b = _segs(x)
     assert out.C == Cout and (out.N, out.H, out.W) == (a.N, a.H, a.W) and out.dtype == a.dtype
     dev, st = _env(a.buf)
@@ -161,7 +162,7 @@ def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, a
     with _Timed("conv_fwd"):
         call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
              a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), out.ptr, out.ld, mask.ptr if mask else None,
-             mask.ld if mask else 0, flags, dev, st)
+             mask.ld if mask else 0, mask.C if mask else 0, flags, dev, st)
     return out
 
 

@@ -74,6 +74,12 @@ def test_conv_fwd_dgrad_wgrad(dtype, case):
     ops.conv_fwd(dya, wb, Cin, dx, mask=ma, accumulate=True)
     t2 = dict(TOL[dtype]); t2["atol"] *= 2
     report("conv_dgrad_accum", from_act(dx), 2 * ref_dx, **t2)
+    # mask on the leading channels only (a concat of a ReLU output and an unmasked skip tensor)
+    mc = max(8, Cin // 2 // 8 * 8)
+    ops.conv_fwd(dya, wb, Cin, dx, mask=ops.Act(ma.buf, 0, mc))
+    ref_part = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
+    ref_part[:, :mc] *= (mask[:, :mc] > 0)
+    report("conv_dgrad_partial_mask", from_act(dx), ref_part, **TOL[dtype])
     # weight gradient
     dw = torch.empty(Cout, Cin, 3, 3, device="cuda")
     ops.conv_wgrad(xa, dya, dw)
