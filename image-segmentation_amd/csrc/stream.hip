@@ -292,6 +292,179 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
     }
 }
 
+// ------------------------------------------------------------------------------ norm + ReLU + 2x2 max pool, fused
+// The last BatchNorm of an encoder stage feeds both the skip connection and the stage's max pool.  One thread owns a
+// 2x2 window (8 channels): the forward writes the four activations and their maximum in one pass; the backward routes
+// the pooled gradient to the window's first maximum (scan order, compared at storage precision exactly as a separate
+// pool kernel would see the stored activations), adds the skip gradient and continues with the norm backward, so the
+// full-resolution gradient is never written and re-read in between.
+struct Window { int64_t p00; int64_t q; };   // first pixel of the window, window index (= pooled pixel)
+__device__ __forceinline__ int64_t window_pixel(int64_t q, int H, int W) {
+    const int Wo = W / 2, Ho = H / 2;
+    const int ox = (int)(q % Wo);
+    const int64_t t = q / Wo;
+    const int oy = (int)(t % Ho);
+    const int64_t n = t / Ho;
+    return (n * H + 2 * oy) * W + 2 * ox;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void norm_pool_apply_kernel(const T* __restrict__ x, int64_t ldx, int64_t Q, int H, int W,
+                                                                   int C, const float* __restrict__ stats,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, T* __restrict__ y,
+                                                                   int64_t ldy, T* __restrict__ pool, int64_t ldp) {
+    const int cv = C / 8, rows = kThreads / cv;
+    const int v = threadIdx.x % cv, r = threadIdx.x / cv;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        const float mean = stats[c * 2], rstd = stats[c * 2 + 1];
+        sc[j] = rstd * (gamma ? gamma[c] : 1.f);
+        sh[j] = (beta ? beta[c] : 0.f) - mean * sc[j];
+    }
+    for (int64_t q = (int64_t)blockIdx.x * rows + r; q < Q && r < rows; q += (int64_t)gridDim.x * rows) {
+        const int64_t p00 = window_pixel(q, H, W);
+        const int64_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+        float a[4][8], m[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Elem<T>::load8(x + off[k] * ldx + v * 8, a[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a[k][j] = fmaxf(a[k][j] * sc[j] + sh[j], 0.f);
+                m[j] = k == 0 ? a[k][j] : fmaxf(m[j], a[k][j]);
+            }
+            Elem<T>::store8(y + off[k] * ldy + v * 8, a[k]);
+        }
+        Elem<T>::store8(pool + q * ldp + v * 8, m);
+    }
+}
+
+// gradient reaching the norm output at the four pixels of window q (masked by the ReLU), and the normalised inputs
+template <typename T>
+__device__ __forceinline__ void window_grad(const T* __restrict__ da, int64_t ld_da, const T* __restrict__ dp, int64_t ld_dp,
+                                            const T* __restrict__ x, int64_t ldx, int64_t q, const int64_t (&off)[4], int v,
+                                            const float (&mean)[8], const float (&rstd)[8], const float (&ga)[8],
+                                            const float (&be)[8], float (&g)[4][8], float (&xh)[4][8]) {
+    float pre[4][8], gp[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Elem<T>::load8(x + off[k] * ldx + v * 8, pre[k]);
+    Elem<T>::load8(dp + q * ld_dp + v * 8, gp);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (da) Elem<T>::load8(da + off[k] * ld_da + v * 8, g[k]);
+        else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[k][j] = 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float sc = rstd[j] * ga[j], sh = be[j] - mean[j] * sc;
+        float act[4];
+        int arg = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            xh[k][j] = (pre[k][j] - mean[j]) * rstd[j];
+            pre[k][j] = pre[k][j] * sc + sh;                                   // same expression as the forward
+            act[k] = Elem<T>::to_f(Elem<T>::from_f(fmaxf(pre[k][j], 0.f)));   // the stored activation
+            if (k > 0 && act[k] > act[arg]) arg = k;                           // first maximum in scan order wins
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = g[k][j] + (k == arg ? gp[j] : 0.f);
+            g[k][j] = pre[k][j] > 0.f ? t : 0.f;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void norm_pool_bwd_partial_kernel(const T* __restrict__ da, int64_t ld_da,
+                                                                         const T* __restrict__ dp, int64_t ld_dp,
+                                                                         const T* __restrict__ x, int64_t ldx, int64_t Q, int H,
+                                                                         int W, int C, const float* __restrict__ stats,
+                                                                         const float* __restrict__ gamma,
+                                                                         const float* __restrict__ beta, int bpg,
+                                                                         float* __restrict__ ws) {
+    __shared__ float red[kThreads][17];
+    const int cv = C / 8, rows = kThreads / cv;
+    const int v = threadIdx.x % cv, r = threadIdx.x / cv;
+    const int b = blockIdx.x;
+    float mean[8], rstd[8], ga[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        mean[j] = stats[c * 2];
+        rstd[j] = stats[c * 2 + 1];
+        ga[j] = gamma ? gamma[c] : 1.f;
+        be[j] = beta ? beta[c] : 0.f;
+    }
+    const int64_t per = (Q + bpg - 1) / bpg;
+    const int64_t lo = (int64_t)b * per, hi = (lo + per < Q) ? lo + per : Q;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+    for (int64_t q = lo + r; q < hi && r < rows; q += rows) {
+        const int64_t p00 = window_pixel(q, H, W);
+        const int64_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+        float g[4][8], xh[4][8];
+        window_grad<T>(da, ld_da, dp, ld_dp, x, ldx, q, off, v, mean, rstd, ga, be, g, xh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += g[k][j]; s2[j] += g[k][j] * xh[k][j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][8 + j] = s2[j]; }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += kThreads) {
+        const int k = t / C, c = t % C;
+        float acc = 0.f;
+        for (int rr = 0; rr < rows; ++rr) acc += red[rr * cv + c / 8][k * 8 + (c & 7)];
+        ws[((int64_t)b * 2 + k) * C + c] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void norm_pool_bwd_dx_kernel(const T* __restrict__ da, int64_t ld_da,
+                                                                    const T* __restrict__ dp, int64_t ld_dp,
+                                                                    const T* __restrict__ x, int64_t ldx, int64_t Q, int H, int W,
+                                                                    int C, int64_t M, const float* __restrict__ stats,
+                                                                    const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, int frozen,
+                                                                    const float* __restrict__ red, T* __restrict__ dx,
+                                                                    int64_t ld_dx) {
+    const int cv = C / 8, rows = kThreads / cv;
+    const int v = threadIdx.x % cv, r = threadIdx.x / cv;
+    float mean[8], rstd[8], ga[8], be[8], m1[8], m2[8];
+    const float invM = 1.f / (float)M;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        mean[j] = stats[c * 2];
+        rstd[j] = stats[c * 2 + 1];
+        ga[j] = gamma ? gamma[c] : 1.f;
+        be[j] = beta ? beta[c] : 0.f;
+        m1[j] = frozen ? 0.f : red[c * 2] * invM;
+        m2[j] = frozen ? 0.f : red[c * 2 + 1] * invM;
+    }
+    for (int64_t q = (int64_t)blockIdx.x * rows + r; q < Q && r < rows; q += (int64_t)gridDim.x * rows) {
+        const int64_t p00 = window_pixel(q, H, W);
+        const int64_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+        float g[4][8], xh[4][8];
+        window_grad<T>(da, ld_da, dp, ld_dp, x, ldx, q, off, v, mean, rstd, ga, be, g, xh);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[k][j] = rstd[j] * ga[j] * (g[k][j] - m1[j] - xh[k][j] * m2[j]);
+            Elem<T>::store8(dx + off[k] * ld_dx + v * 8, g[k]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------ 2x2 max pool
 template <typename T>
 __global__ __launch_bounds__(kThreads) void maxpool_fwd_kernel(const T* __restrict__ x, int64_t ldx, int64_t N, int H, int W,
@@ -915,6 +1088,64 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
         SEGK_REQUIRE(!frozen, SEGK_EINVAL, "norm_bwd: bias gradient with frozen statistics: use segk_colsum on dx");
         if (!accumulate) SEGK_HIP(hipMemsetAsync(dbias_out, 0, (size_t)C * sizeof(float), st));
     }
+    return SEGK_OK;
+}
+
+extern "C" int segk_norm_pool_apply(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
+                                    const float* stats, const float* gamma, const float* beta, void* y, int64_t ldy, void* pool,
+                                    int64_t ld_pool, int dev, void* stream) {
+    SEGK_CHECK_ACT("norm_pool_apply(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("norm_pool_apply(y)", y, ldy, C, dtype);
+    SEGK_CHECK_ACT("norm_pool_apply(pool)", pool, ld_pool, C, dtype);
+    if (int rc = check_norm_c("norm_pool_apply", C)) return rc;
+    SEGK_REQUIRE(stats && N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SEGK_ESHAPE,
+                 "norm_pool_apply: H and W must be even (H=%lld W=%lld)", (long long)H, (long long)W);
+    SEGK_HIP(use_device(dev));
+    const int64_t Q = N * (H / 2) * (W / 2);
+    const int rows = kThreads / (int)(C / 8);
+    int64_t gx = (Q + rows - 1) / rows;
+    if (gx > 8192) gx = 8192;
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_apply_kernel<T>), dim3((unsigned)gx), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, stats, gamma, beta,
+                                                     (T*)y, ldy, (T*)pool, ld_pool));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_norm_pool_bwd(int dtype, const void* dy, int64_t ld_dy, const void* dpool, int64_t ld_dpool, const void* x,
+                                  int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C, const float* stats,
+                                  const float* gamma, const float* beta, int flags, void* dx, int64_t ld_dx, float* dgamma,
+                                  float* dbeta, void* workspace, size_t workspace_bytes, int dev, void* stream) {
+    if (dy) SEGK_CHECK_ACT("norm_pool_bwd(dy)", dy, ld_dy, C, dtype);
+    SEGK_CHECK_ACT("norm_pool_bwd(dpool)", dpool, ld_dpool, C, dtype);
+    SEGK_CHECK_ACT("norm_pool_bwd(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("norm_pool_bwd(dx)", dx, ld_dx, C, dtype);
+    if (int rc = check_norm_c("norm_pool_bwd", C)) return rc;
+    SEGK_REQUIRE(stats && workspace && N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SEGK_ESHAPE,
+                 "norm_pool_bwd: H and W must be even (H=%lld W=%lld)", (long long)H, (long long)W);
+    SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "norm_pool_bwd: dgamma/dbeta come in pairs");
+    const int64_t M = N * H * W, Q = M / 4;
+    SEGK_REQUIRE(workspace_bytes >= segk_norm_workspace(1, M, C), SEGK_EWORKSPACE, "norm_pool_bwd: workspace too small");
+    SEGK_HIP(use_device(dev));
+    hipStream_t st = (hipStream_t)stream;
+    const int bpg = stats_bpg(1, Q, C);
+    const int accumulate = (flags >> 1) & 1, frozen = (flags >> 2) & 1;
+    float* part = (float*)workspace;
+    float* red = (float*)((char*)workspace + align_up((size_t)bpg * 2 * C * sizeof(float), 256));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_bwd_partial_kernel<T>), dim3(bpg), dim3(kThreads), 0, st, (const T*)dy, ld_dy,
+                                                     (const T*)dpool, ld_dpool, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, stats, gamma,
+                                                     beta, bpg, part));
+    SEGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)((C + 3) / 4), 1), dim3(kThreads), 0, st, (const float*)part, bpg, (int)C,
+                       red, dgamma, dbeta, accumulate);
+    SEGK_LAUNCH_CHECK();
+    const int rows = kThreads / (int)(C / 8);
+    int64_t gx = (Q + rows - 1) / rows;
+    if (gx > 8192) gx = 8192;
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_bwd_dx_kernel<T>), dim3((unsigned)gx), dim3(kThreads), 0, st, (const T*)dy,
+                                                     ld_dy, (const T*)dpool, ld_dpool, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, M, stats,
+                                                     gamma, beta, frozen, (const float*)red, (T*)dx, ld_dx));
+    SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 

@@ -119,22 +119,24 @@ class _UNetVggBase(SegkNet):
         else:
             v = None
         skips = {}
+        pooled = None
         for k, (first, stage_widths) in enumerate(_ENCODER, start=1):
             idx = first + (1 if first else 0)
             if first:
-                v = rt.pool(v)
+                v = pooled           # the max pool that opens this stage ran fused with the previous stage's last norm
             for j, _ in enumerate(stage_widths):
                 wn, bn_ = f"conv{k}.{idx}", f"conv{k}.{idx + 1}"
                 if k == 1 and j == 0 and v is None:
                     y = rt.conv_first(x, wn + ".weight", wn + ".bias", bias_grad_zero=self.training)
                 else:
                     y = rt.conv(v, wn + ".weight", wn + ".bias", bias_grad_zero=self.training)
-                last = j == len(stage_widths) - 1
-                out = Act(cat[k], widths[k][0], widths[k][1]) if last else None
-                v = rt.bn_relu(y, bn_, out=out)
+                if j == len(stage_widths) - 1:   # skip tensor (second slice of the concat buffer) + pool for the next stage
+                    v, pooled = rt.bn_relu(y, bn_, out=Act(cat[k], widths[k][0], widths[k][1]), pool=True)
+                else:
+                    v = rt.bn_relu(y, bn_)
                 idx += 3
             skips[k] = v
-        d = self.center[1].emit(rt, "center.1.", rt.pool(skips[5]), out=Act(cat[5], 0, widths[5][0]))
+        d = self.center[1].emit(rt, "center.1.", pooled, out=Act(cat[5], 0, widths[5][0]))
         for k in (5, 4, 3, 2):
             block = getattr(self, f"dec{k}")
             d = block.emit(rt, f"dec{k}.", [d, skips[k]], out=Act(cat[k - 1], 0, widths[k - 1][0]))

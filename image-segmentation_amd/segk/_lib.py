@@ -47,6 +47,8 @@ _PROTOS = {
     "segk_norm_apply": (I, [I, P, L, L, L, L, P, P, P, I, P, L, I, P]),
     "segk_norm_eval_stats": (I, [P, P, L, F, P, I, P]),
     "segk_norm_bwd": (I, [I, P, L, P, L, L, L, L, P, P, P, I, P, L, P, P, P, P, Z, I, P]),
+    "segk_norm_pool_apply": (I, [I, P, L, L, L, L, L, P, P, P, P, L, P, L, I, P]),
+    "segk_norm_pool_bwd": (I, [I, P, L, P, L, P, L, L, L, L, L, P, P, P, I, P, L, P, P, P, Z, I, P]),
     "segk_maxpool2x2_fwd": (I, [I, P, L, L, L, L, L, P, L, I, P]),
     "segk_maxpool2x2_bwd": (I, [I, P, L, P, L, L, L, L, L, P, L, I, I, P]),
     "segk_upsample2x_fwd": (I, [I, P, L, L, L, L, L, P, I, P, L, I, P]),

@@ -234,8 +234,9 @@ class Runtime:
         self.record(bwd)
         return u
 
-    def bn_relu(self, y, prefix, out=None, eps=1e-5, momentum=0.1):
-        """BatchNorm2d (+ReLU).  Training: batch statistics and running-buffer update; eval: running buffers."""
+    def bn_relu(self, y, prefix, out=None, eps=1e-5, momentum=0.1, pool=False):
+        """BatchNorm2d (+ReLU).  Training: batch statistics and running-buffer update; eval: running buffers.
+        pool=True also returns the 2x2 max pool of the result, computed (and back-propagated) in the same passes."""
         C = y.act.C
         gamma, beta = self.p[prefix + ".weight"].detach(), self.p[prefix + ".bias"].detach()
         stats = torch.empty(2 * C, dtype=torch.float32, device=self.device)
@@ -245,19 +246,28 @@ class Runtime:
         else:
             ops.norm_eval_stats(self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], eps, stats)
         a = Var(out or self.new(y.act.N, y.act.H, y.act.W, C))
-        ops.norm_apply(y.act, 1, stats, gamma, beta, True, a.act)
+        p = None
+        if pool:
+            p = Var(self.new(y.act.N, y.act.H // 2, y.act.W // 2, C))
+            ops.norm_pool_apply(y.act, stats, gamma, beta, a.act, p.act)
+        else:
+            ops.norm_apply(y.act, 1, stats, gamma, beta, True, a.act)
         frozen = not self.training
 
         def bwd():
-            da = self.grad_of(a.act)
             dy = self.grad_of(y.act)
             dg, db = self.alloc_grad(prefix + ".weight", gamma), self.alloc_grad(prefix + ".bias", beta)
-            ops.norm_bwd(da, y.act, 1, stats, gamma, beta, True, dy, dgamma=dg, dbeta=db, frozen=frozen)
+            if pool:
+                assert p.ready, "the pooled tensor received no gradient"
+                da = self.grad_of(a.act) if a.ready else None
+                ops.norm_pool_bwd(da, self.grad_of(p.act), y.act, stats, gamma, beta, dy, dgamma=dg, dbeta=db, frozen=frozen)
+            else:
+                ops.norm_bwd(self.grad_of(a.act), y.act, 1, stats, gamma, beta, True, dy, dgamma=dg, dbeta=db, frozen=frozen)
             y.ready = True
             self._emit(prefix + ".weight", dg)
             self._emit(prefix + ".bias", db)
         self.record(bwd)
-        return a
+        return (a, p) if pool else a
 
     def pool(self, a, out=None):
         assert not a.relu_fused, "max pool cannot consume a tensor whose ReLU backward is deferred"

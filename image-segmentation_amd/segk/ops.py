@@ -285,6 +285,25 @@ def norm_bwd(dy, x, groups, stats, gamma, beta, relu, dx, dgamma=None, dbeta=Non
     return dx
 
 
+def norm_pool_apply(x, stats, gamma, beta, out, pool):
+    """out = relu(batchnorm(x)), pool = maxpool2x2(out) in one pass."""
+    dev, st = _env(x.buf)
+    call("segk_norm_pool_apply", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, stats.data_ptr(), _p(gamma), _p(beta),
+         out.ptr, out.ld, pool.ptr, pool.ld, dev, st)
+    return out, pool
+
+
+def norm_pool_bwd(dy, dpool, x, stats, gamma, beta, dx, dgamma=None, dbeta=None, accumulate=False, frozen=False):
+    """Backward of norm_pool_apply: dy (gradient of `out` from its other consumers) may be None."""
+    dev, st = _env(x.buf)
+    ws = workspace(query("segk_norm_workspace", 1, x.P, x.C), x.device)
+    flags = (ACCUM if accumulate else 0) | (FROZEN if frozen else 0)
+    call("segk_norm_pool_bwd", dt(x.dtype), dy.ptr if dy is not None else None, dy.ld if dy is not None else 0, dpool.ptr,
+         dpool.ld, x.ptr, x.ld, x.N, x.H, x.W, x.C, stats.data_ptr(), _p(gamma), _p(beta), flags, dx.ptr, dx.ld, _p(dgamma),
+         _p(dbeta), ws.data_ptr(), ws.numel(), dev, st)
+    return dx
+
+
 # ------------------------------------------------------------------------------------ resampling
 def maxpool_fwd(x, out):
     dev, st = _env(x.buf)

@@ -214,6 +214,22 @@ int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const void* x, int64
                   void* dx, int64_t ld_dx, float* dgamma, float* dbeta, float* dbias_out, void* workspace,
                   size_t workspace_bytes, int dev, void* stream);
 
+/* BatchNorm (batch or running statistics in `stats`) + ReLU + the 2x2/stride-2 max pool behind it, one pass:
+ * y = relu(norm(x)) [N,H,W,C] and pool = maxpool2x2(y) [N,H/2,W/2,C].
+ * replaces: the last BatchNorm2d/ReLU of an encoder stage together with the MaxPool2d that opens the next one
+ *           (models/unetvgg.py:72-79; models/unetplusplus.py:35,45-58).
+ * segk_norm_pool_bwd: dx = d loss / d x from dy (gradient reaching y from its other consumers, e.g. the skip
+ * connection; may be NULL) and dpool (gradient of the pooled tensor, routed to each window's first maximum);
+ * dgamma/dbeta as segk_norm_bwd.  flags bit1: accumulate dgamma/dbeta, bit2: frozen (running) statistics.
+ * workspace: segk_norm_workspace(1, N*H*W, C) bytes.                                               */
+int segk_norm_pool_apply(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
+                         const float* stats, const float* gamma, const float* beta, void* y, int64_t ldy, void* pool,
+                         int64_t ld_pool, int dev, void* stream);
+int segk_norm_pool_bwd(int dtype, const void* dy, int64_t ld_dy, const void* dpool, int64_t ld_dpool, const void* x,
+                       int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C, const float* stats, const float* gamma,
+                       const float* beta, int flags, void* dx, int64_t ld_dx, float* dgamma, float* dbeta,
+                       void* workspace, size_t workspace_bytes, int dev, void* stream);
+
 /* 2x2/stride-2 max pool (models/unetvgg.py:73-79 VGG pools; models/unetplusplus.py:35).           */
 int segk_maxpool2x2_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
                         void* y, int64_t ldy, int dev, void* stream);

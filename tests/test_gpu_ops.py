@@ -203,6 +203,56 @@ def test_batchnorm_relu_fwd_bwd(dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 64, 24, 16), (3, 40, 8, 12), (1, 256, 4, 6)], ids=str)
+@pytest.mark.parametrize("skip_grad", [True, False], ids=["skip", "noskip"])
+def test_batchnorm_relu_maxpool_fused(dtype, shape, skip_grad):
+    """BatchNorm+ReLU with the 2x2 max pool behind it in one pass (forward and backward): against ATen in fp32,
+    and against the separate norm / pool kernels (same rounding points) in both dtypes."""
+    from segk import ops
+    from util import rel_l2
+    N, C, H, W = shape
+    x = (rnd(shape, dtype, 41) * 1.5 + 0.3).to(dtype).float()
+    gamma, beta = rnd((C,), torch.float32, 42) * 0.2 + 1.0, rnd((C,), torch.float32, 43) * 0.2
+    dy = rnd(shape, dtype, 44)
+    dp = rnd((N, C, H // 2, W // 2), dtype, 45)
+    xa = to_act(x, dtype, ld=C + 8, c0=8)
+    stats = torch.empty(2 * C, device="cuda")
+    ops.norm_stats(xa, 1, 1e-5, stats)
+    g, b = gamma.cuda(), beta.cuda()
+    out = ops.Act(torch.zeros(N, H, W, C + 16, dtype=dtype, device="cuda"), 16, C)
+    pool = ops.Act.empty(N, H // 2, W // 2, C, dtype, "cuda")
+    ops.norm_pool_apply(xa, stats, g, b, out, pool)
+    # separate kernels
+    out2 = ops.Act.empty(N, H, W, C, dtype, "cuda")
+    pool2 = ops.Act.empty(N, H // 2, W // 2, C, dtype, "cuda")
+    ops.norm_apply(xa, 1, stats, g, b, True, out2)
+    ops.maxpool_fwd(out2, pool2)
+    assert torch.equal(from_act(out), from_act(out2)) and torch.equal(from_act(pool), from_act(pool2))
+    dya, dpa = to_act(dy, dtype), to_act(dp, dtype)
+    dx = ops.Act.empty(N, H, W, C, dtype, "cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.norm_pool_bwd(dya if skip_grad else None, dpa, xa, stats, g, b, dx, dgamma=dg, dbeta=db)
+    da2 = to_act(dy if skip_grad else torch.zeros_like(dy), dtype)
+    ops.maxpool_bwd(out2, dpa, da2, accumulate=True)
+    dx2 = ops.Act.empty(N, H, W, C, dtype, "cuda")
+    dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.norm_bwd(da2, xa, 1, stats, g, b, True, dx2, dgamma=dg2, dbeta=db2)
+    bound = 1e-5 if dtype == torch.float32 else 1e-2     # bf16: the separate path rounds the summed gradient once more
+    assert rel_l2(from_act(dx), from_act(dx2)) < bound
+    assert rel_l2(dg, dg2) < bound and rel_l2(db, db2) < bound
+    if dtype == torch.float32:
+        xd = x.double().requires_grad_(True)
+        gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+        a = F.relu(F.batch_norm(xd, None, None, gd, bd, True, 0.1, 1e-5))
+        report("bn_pool_fwd", from_act(pool), F.max_pool2d(a, 2).float(), **TOL[dtype])
+        loss = (F.max_pool2d(a, 2) * dp.double()).sum() + ((a * dy.double()).sum() if skip_grad else 0.0)
+        loss.backward()
+        report("bn_pool_bwd_dx", from_act(dx), xd.grad.float(), **TOL[dtype])
+        report("bn_pool_dgamma", dg.cpu(), gd.grad.float(), rtol=1e-4, atol=1e-4 * (N * H * W) ** 0.5)
+        report("bn_pool_dbeta", db.cpu(), bd.grad.float(), rtol=1e-4, atol=1e-4 * (N * H * W) ** 0.5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("align", [False, True], ids=["ac0", "ac1"])
 def test_instnorm_upsample_relu(dtype, align):
     from segk import ops
