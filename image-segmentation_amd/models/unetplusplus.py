@@ -30,8 +30,9 @@ class conv_block_nested(SegkBlock):
         x = self.activation(self.bn1(self.conv1(x)))
         return self.activation(self.bn2(self.conv2(x)))
 
-    def emit(self, rt, prefix, x, out=None, image=None):
-        """Append the block to a segk tape.  x: Var / concat description; image: raw NCHW input of the first block."""
+    def emit(self, rt, prefix, x, out=None, image=None, pool=False):
+        """Append the block to a segk tape.  x: Var / concat description; image: raw NCHW input of the first block;
+        pool=True returns (output, maxpool2x2(output)), the pool fused into the last norm's passes."""
         zero = rt.training     # a bias in front of a batch-statistics norm has an identically zero gradient
         if image is not None:
             y = rt.conv_first(image, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero)
@@ -39,7 +40,7 @@ class conv_block_nested(SegkBlock):
             y = rt.conv(x, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero)
         h = rt.bn_relu(y, prefix + "bn1")
         y = rt.conv(h, prefix + "conv2.weight", prefix + "conv2.bias", bias_grad_zero=zero)
-        return rt.bn_relu(y, prefix + "bn2", out=out)
+        return rt.bn_relu(y, prefix + "bn2", out=out, pool=pool)
 
     def _emit_block(self, rt, v):
         return self.emit(rt, "", v)
@@ -84,17 +85,19 @@ class Nested_UNet(SegkNet):
         f = _WIDTHS
         # level i keeps nodes j = 0 .. 3-i side by side (the ones later convolutions concatenate)
         level = {i: rt.new(N, H >> i, W >> i, f[i] * (4 - i)).buf for i in range(4)}
-        node = {}
+        node, pooled = {}, {}
         for i, j in self._schedule():
             block = getattr(self, f"conv{i}_{j}")
             out = Act(level[i], f[i] * j, f[i]) if (i < 4 and j < 4 - i) else None
             if j == 0:
+                # backbone node: its max pool (input of the next backbone node) comes out of the same passes
                 if i == 0 and 9 * cin <= 32:
-                    node[0, 0] = block.emit(rt, "conv0_0.", None, out=out, image=x)
+                    res = block.emit(rt, "conv0_0.", None, out=out, image=x, pool=True)
                 elif i == 0:
-                    node[0, 0] = block.emit(rt, "conv0_0.", rt.input(x), out=out)
+                    res = block.emit(rt, "conv0_0.", rt.input(x), out=out, pool=True)
                 else:
-                    node[i, 0] = block.emit(rt, f"conv{i}_0.", rt.pool(node[i - 1, 0]), out=out)
+                    res = block.emit(rt, f"conv{i}_0.", pooled[i - 1], out=out, pool=i < 4)
+                node[i, 0], pooled[i] = res if i < 4 else (res, None)
             else:
                 up = rt.up(node[i + 1, j - 1], align=True)
                 node[i, j] = block.emit(rt, f"conv{i}_{j}.", ([node[i, k] for k in range(j)], up), out=out)
