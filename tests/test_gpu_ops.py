@@ -88,6 +88,51 @@ def test_conv_fwd_dgrad_wgrad(dtype, case):
     report("conv_wgrad", dw.cpu(), ref_dw, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * max(scale, 1.0) * 0.05)
 
 
+THIN_CASES = [
+    # N, H, W, C0, C1, Cout: enough 16x16 tiles (>= 2 per CU) for the resident-weight kernel of thin bf16 layers
+    (2, 256, 256, 64, 0, 64),     # one K-row, 64-channel block; its data gradient takes the same kernel
+    (2, 200, 328, 64, 0, 128),    # ragged borders, two channel blocks
+    (2, 208, 320, 32, 64, 32),    # two segments (half K-row + K-row), 32-channel block; data gradient: 3 blocks of 32
+    (2, 256, 272, 128, 0, 32),    # two K-rows
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_thin_layers_bf16(case):
+    """Thin layers at sizes where the resident-weight kernel is selected: forward (+bias, ReLU), data gradient
+    (+leading-channel mask, accumulate) against ATen in fp64."""
+    from segk import ops
+    dtype = torch.bfloat16
+    N, H, W, C0, C1, Cout = case
+    Cin = C0 + C1
+    x = rnd((N, Cin, H, W), dtype, 51)
+    w = rnd((Cout, Cin, 3, 3), dtype, 52, scale=(2.0 / (9 * Cin)) ** 0.5)
+    b = rnd((Cout,), torch.float32, 53)
+    dy = rnd((N, Cout, H, W), dtype, 54)
+    wf, wb = ops.conv_pack(w.cuda(), dtype, seg0=C0 if C1 else 0)
+    if C1:
+        xin = (to_act(x[:, :C0], dtype, ld=C0 + 8, c0=8), to_act(x[:, C0:], dtype))
+    else:
+        xin = to_act(x, dtype, ld=Cin + 16, c0=8)
+    out = ops.Act.empty(N, H, W, Cout, dtype, "cuda")
+    ops.conv_fwd(xin, wf, Cout, out, bias=b.cuda(), relu=True)
+    ref = F.relu(F.conv2d(x.double(), w.double(), b.double(), padding=1)).float()
+    report("thin_fwd", from_act(out), ref, **TOL[dtype])
+    mask = rnd((N, Cin, H, W), dtype, 55)
+    mc = max(8, Cin // 2 // 8 * 8)
+    ma = to_act(mask[:, :mc], dtype)
+    dya = to_act(dy, dtype, ld=Cout + 8)
+    dx = ops.Act(torch.zeros(N, H, W, Cin + 8, dtype=dtype, device="cuda"), 8, Cin)
+    ops.conv_fwd(dya, wb, Cin, dx, mask=ma)
+    ref_dx = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
+    ref_dx[:, :mc] *= (mask[:, :mc] > 0)
+    report("thin_dgrad", from_act(dx), ref_dx, **TOL[dtype])
+    ops.conv_fwd(dya, wb, Cin, dx, mask=ma, accumulate=True)
+    t2 = dict(TOL[dtype]); t2["atol"] *= 2
+    report("thin_dgrad_accum", from_act(dx), 2 * ref_dx, **t2)
+    assert float(dx.buf[..., :8].float().abs().max()) == 0.0, "wrote outside the output slice"
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_conv_two_segments(dtype):
     from segk import ops
