@@ -105,8 +105,17 @@ class FlatModel:
         if broadcast and self.buckets.world > 1:
             import torch.distributed as dist
             dist.broadcast(self.flat_param, src=0, group=group)
-            for b in net.buffers():
-                dist.broadcast(b, src=0, group=group)
+            # BatchNorm buffers: one coalesced broadcast per dtype instead of one per tensor
+            for dtype in (torch.float32, torch.int64):
+                bufs = [b for b in net.buffers() if b.dtype == dtype]
+                if not bufs:
+                    continue
+                flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+                dist.broadcast(flat, src=0, group=group)
+                off = 0
+                for b in bufs:
+                    b.data.copy_(flat[off:off + b.numel()].view_as(b))
+                    off += b.numel()
         net._segk_grad_hooks = (self._sink, self._alloc, self._begin, self._finish)
 
     # hooks called by the tape
