@@ -27,6 +27,12 @@ template <typename T> struct KRow { static constexpr int kElems = kRowBytes / (i
 
 typedef uint4 Slot;   // 16 bytes
 
+// Packed weight images keep their rows (output channels of the forward image, input channels of the data-gradient
+// image) in MFMA order: row r of the 16-row tile t of a 32-row group holds channel 8*(r/4) + 4*(t%2) + r%4 of that
+// group.  A lane of the 16x16 MFMA output owns rows 4g..4g+3 of every tile, so across the two tiles of a group it
+// owns the EIGHT consecutive channels 8g..8g+7 and the epilogues move 16 bytes (bf16) per lane and pixel.
+__host__ __device__ inline int row_channel(int row) { return (row & ~31) + 8 * ((row & 15) >> 2) + 4 * ((row >> 4) & 1) + (row & 3); }
+
 // A strided window onto an NHWC image: logical pixel (y, x) of the convolution grid is physical pixel
 // (y*sy + oy, x*sx + ox) of an image with PH x PW pixels.  Identity for ordinary convolutions; the four
 // phases of a stride-2 transposed convolution read/write every other row and column.
@@ -104,7 +110,7 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 }
 
 template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES>
-__global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(const ConvArgs a) {
     constexpr int PAD = TAPS == 1 ? 0 : 1;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_;
     constexpr int HSLOTS = HPIX * 8;
@@ -251,39 +257,42 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
         }
     }
 
-    // ---- epilogue: bias, ReLU, mask, store 4 consecutive channels per lane --------------------------
+    // ---- epilogue: bias, ReLU, mask, store 8 consecutive channels per lane (rows are in MFMA order) ----------
+    static_assert(NI % 2 == 0, "channel tiles come in pairs");
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
         if (yy >= a.H || xx >= a.W) continue;
         const int64_t pix = a.vout.pixel(n, yy, xx);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int co = cb * BN + wco * WCO + i * 16 + 4 * g;
+        for (int k2 = 0; k2 < NI / 2; ++k2) {
+            const int co = cb * BN + wco * WCO + 32 * k2 + 8 * g;
             if (co >= a.Cout) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e]; v[4 + e] = acc[2 * k2 + 1][j][e]; }
             if (a.bias) {
-                const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
-                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+                const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
             }
             if (a.relu) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+                for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
             }
             if (a.mask && co < a.mask_c) {
-                float m[4];
-                Elem<T>::load4(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
+                float m[8];
+                Elem<T>::load8(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
+                for (int r = 0; r < 8; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
             }
             T* dst = reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
             if (a.accumulate) {
-                float o[4];
-                Elem<T>::load4(dst, o);
+                float o[8];
+                Elem<T>::load8(dst, o);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += o[r];
+                for (int r = 0; r < 8; ++r) v[r] += o[r];
             }
-            Elem<T>::store4(dst, v);
+            Elem<T>::store8(dst, v);
         }
     }
 }
@@ -299,10 +308,6 @@ __global__ __launch_bounds__(kConvThreads) void conv_fwd_kernel(const ConvArgs a
 // Wave w owns tile rows 4w .. 4w+3 and all BN output channels.  One wave per SIMD means that nothing but the
 // wave's own instruction order hides latency, hence the explicit software pipeline below and the effort to keep
 // the per-tile address arithmetic short.
-//
-// Weight rows are permuted on their way into LDS: row r of MFMA tile i holds output channel
-// 32*(i/2) + 8*(r/4) + 4*(i%2) + r%4, so that the accumulators of tiles 2k and 2k+1 in lane (g, *) are the EIGHT
-// consecutive channels 32k + 8g .. +7 and the epilogue stores 16 bytes per lane.
 template <typename T, int BN>
 __global__ __launch_bounds__(kConvThreads) void conv_res_kernel(const ConvArgs a, const int streams) {
     constexpr int TAPS = 9, TH = 16, PAD = 1;
@@ -356,16 +361,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_res_kernel(const ConvArgs a
         if (k < HL - 1 || hyx[k] >= 0) glds16_hidden(src, lds0 + buf * HBYTES + (k * kConvThreads + wave * 64) * 16);
     };
 
-    // ---- prologue: every weight of this channel block (rows permuted, see above), halo of the first tile -------
+    // ---- prologue: every weight of this channel block, halo of the first tile ---------------------------------
     for (int blk = 0; blk < a.nch * TAPS; ++blk) {
+        const char* src = a.w + ((int64_t)blk * a.cout_pad + (int64_t)cb * BN) * kRowBytes + (int64_t)tid * 16;
 #pragma unroll
-        for (int k = 0; k < BN * 8 / kConvThreads; ++k) {
-            const int R = k * (kConvThreads / 8) + (tid >> 3), p = tid & 7;
-            const int ti = R >> 4, r = R & 15;
-            const int srow = (ti >> 1) * 32 + 8 * (r >> 2) + 4 * (ti & 1) + (r & 3);
-            const char* src = a.w + ((int64_t)blk * a.cout_pad + (int64_t)cb * BN + srow) * kRowBytes + ((p ^ (R & 7) ^ (srow & 7)) << 4);
-            glds16_hidden(src, lds0 + 2 * HBYTES + (blk * BN * 8 + k * kConvThreads + wave * 64) * 16);
-        }
+        for (int k = 0; k < BN * 8 / kConvThreads; ++k)
+            glds16_hidden(src + k * kConvThreads * 16, lds0 + 2 * HBYTES + (blk * BN * 8 + k * kConvThreads + wave * 64) * 16);
     }
     if (sidx < ntiles) {
         int n, y0, x0;
@@ -536,11 +537,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __
             const int k = chunk * KR + sl * EPS + j;
             int co, ci, t;
             if (fwd) {
-                co = row; t = tap;
+                co = row_channel(row); t = tap;
                 // K index -> logical input channel (-1 inside the zero padding that ends a segment)
                 if (k < k0_pad) ci = k < seg0 ? k : -1;
                 else ci = seg0 + (k - k0_pad);
-            } else { co = k; ci = row; t = taps - 1 - tap; }
+            } else { co = k; ci = row_channel(row); t = taps - 1 - tap; }
             v[j] = (co < Cout && ci >= 0 && ci < Cin) ? w[((int64_t)co * Cin + ci) * taps + t] : 0.f;
         }
         char* dst = (fwd ? wf : wb) + (((int64_t)chunk * taps + tap) * rows + row) * kRowBytes + ((sl ^ (row & 7)) << 4);
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(kConvThreads) void convt_pack_kernel(const float* _
 #pragma unroll
         for (int j = 0; j < EPS; ++j) {
             const int k = chunk * KR + sl * EPS + j;
-            const int co = fwd ? row : k, ci = fwd ? k : row;
+            const int co = fwd ? row_channel(row) : k, ci = fwd ? k : row_channel(row);
             v[j] = (co < Cout && ci < Cin) ? w[(((int64_t)ci * Cout + co) * 4 + ky) * 4 + kx] : 0.f;
         }
         char* dst = (fwd ? wf : wb) + ((int64_t)phase * per + (((int64_t)chunk * 4 + tap) * rows + row) * 8) * 16 + ((sl ^ (row & 7)) << 4);
@@ -927,7 +928,7 @@ static int device_cus(int dev) {
 }
 static bool launch_fwd_resident(int dtype, int taps, ConvArgs a, int dev, hipStream_t st) {
     static const bool off = getenv("SEGK_NO_RESIDENT") != nullptr;
-    if (off || dtype != SEGK_BF16 || taps != 9 || a.H < 16 || a.W < 16 || a.Cout % 8 || (a.mask && a.mask_c % 8)) return false;
+    if (off || dtype != SEGK_BF16 || taps != 9 || a.H < 16 || a.W < 16) return false;
     // one channel block only: with several, every block would re-read the input and the general kernel wins
     int bn;
     if (a.nch == 1 && a.cout_pad <= 64) bn = a.cout_pad;
@@ -1049,12 +1050,12 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_fwd: taps must be 1 or 9");
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_fwd: bad N/H/W");
     SEGK_REQUIRE(w_packed && y && aligned16(w_packed), SEGK_EINVAL, "conv_fwd: null or misaligned weights/output");
-    SEGK_REQUIRE(Cout > 0 && Cout % 4 == 0 && ldy >= Cout, SEGK_ESHAPE, "conv_fwd: Cout %lld must be a multiple of 4 and <= ldy", (long long)Cout);
+    SEGK_REQUIRE(Cout > 0 && Cout % 8 == 0 && ldy >= Cout, SEGK_ESHAPE, "conv_fwd: Cout %lld must be a multiple of 8 and <= ldy", (long long)Cout);
     SEGK_REQUIRE(aligned16(y) && (ldy * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_fwd: output pointer/ld misaligned");
     SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "conv_fwd: bias must be 16-byte aligned");
     SEGK_REQUIRE(!mask || (aligned16(mask) && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "conv_fwd: mask misaligned");
-    SEGK_REQUIRE(!mask || (mask_channels > 0 && mask_channels <= Cout && mask_channels % 4 == 0 && ld_mask >= mask_channels), SEGK_ESHAPE,
-                 "conv_fwd: mask_channels must be a multiple of 4 in (0, Cout] and fit ld_mask");
+    SEGK_REQUIRE(!mask || (mask_channels > 0 && mask_channels <= Cout && mask_channels % 8 == 0 && ld_mask >= mask_channels), SEGK_ESHAPE,
+                 "conv_fwd: mask_channels must be a multiple of 8 in (0, Cout] and fit ld_mask");
     SEGK_HIP(use_device(dev));
     const int kr = krow(dtype);
     ConvArgs a;

@@ -95,8 +95,7 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(const T* __rest
     }
 }
 
-// Fixed-order sum of the per-block partials of one (group, kind, channel): the 64 lanes of a wavefront take the
-// partials round-robin, then a butterfly adds the lanes (same order every run -> deterministic).
+// Fixed-order sum of per-block partials by one wavefront: lanes take the partials round-robin, a butterfly adds them.
 __device__ __forceinline__ double wave_sum_partials(const float* __restrict__ ws, int64_t base, int64_t stride, int bpg) {
     const int lane = threadIdx.x & 63;
     double s = 0.0;
@@ -104,19 +103,32 @@ __device__ __forceinline__ double wave_sum_partials(const float* __restrict__ ws
     return wave_sum_d(s);
 }
 
+// Fixed-order sum of the per-block partials of one (group, kind, channel) by a whole workgroup: thread t adds
+// partials t, t+256, ... in double, a butterfly adds the lanes of each wavefront and wave 0's lane 0 adds the four
+// wave sums -- the same order every run (deterministic), and a latency of one round of loads instead of bpg/64.
+__device__ __forceinline__ double block_sum_partials(const float* __restrict__ ws, int64_t base, int64_t stride, int bpg,
+                                                     double* smem4) {
+    double s = 0.0;
+    for (int b = threadIdx.x; b < bpg; b += kThreads) s += (double)ws[base + (int64_t)b * stride];
+    s = wave_sum_d(s);
+    __syncthreads();                       // smem4 may still be read from a previous call
+    if ((threadIdx.x & 63) == 0) smem4[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return smem4[0] + smem4[1] + smem4[2] + smem4[3];
+}
+
 // mean / rstd per (group, channel) + optional running-buffer update (BatchNorm, groups == 1).
-// One wavefront per channel (4 channels per block).
+// One workgroup per (channel, group).
 __global__ __launch_bounds__(kThreads) void stats_finalize_kernel(const float* __restrict__ ws, int bpg, int64_t M, int C,
                                                                   float eps, float* __restrict__ stats,
                                                                   float* __restrict__ rmean, float* __restrict__ rvar,
                                                                   float momentum) {
-    const int g = blockIdx.y;
-    const int c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double sm[4];
+    const int g = blockIdx.y, c = blockIdx.x;
     const int64_t base = (int64_t)g * bpg * 2 * C + c;
-    const double s = wave_sum_partials(ws, base, 2 * (int64_t)C, bpg);
-    const double q = wave_sum_partials(ws, base + C, 2 * (int64_t)C, bpg);
-    if ((threadIdx.x & 63) != 0) return;
+    const double s = block_sum_partials(ws, base, 2 * (int64_t)C, bpg, sm);
+    const double q = block_sum_partials(ws, base + C, 2 * (int64_t)C, bpg, sm);
+    if (threadIdx.x != 0) return;
     const double mean = s / (double)M;
     double var = q / (double)M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -139,10 +151,10 @@ __global__ __launch_bounds__(kThreads) void eval_stats_kernel(const float* __res
 
 __global__ __launch_bounds__(kThreads) void colsum_finalize_kernel(const float* __restrict__ ws, int bpg, int C,
                                                                    float* __restrict__ out, int accumulate) {
-    const int c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (c >= C) return;
-    const double s = wave_sum_partials(ws, c, 2 * (int64_t)C, bpg);
-    if ((threadIdx.x & 63) == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+    __shared__ double sm[4];
+    const int c = blockIdx.x;
+    const double s = block_sum_partials(ws, c, 2 * (int64_t)C, bpg, sm);
+    if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
 // ------------------------------------------------------------------------------ normalise (+ReLU)
@@ -230,17 +242,16 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __r
     }
 }
 
-// pass 1b: red[(g*C+c)*2 + {0,1}] = {s1, s2}; dgamma/dbeta.  One wavefront per channel.
+// pass 1b: red[(g*C+c)*2 + {0,1}] = {s1, s2}; dgamma/dbeta.  One workgroup per (channel, group).
 __global__ __launch_bounds__(kThreads) void norm_bwd_finalize_kernel(const float* __restrict__ ws, int bpg, int C,
                                                                      float* __restrict__ red, float* __restrict__ dgamma,
                                                                      float* __restrict__ dbeta, int accumulate) {
-    const int g = blockIdx.y;
-    const int c = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
-    if (c >= C) return;
+    __shared__ double sm[4];
+    const int g = blockIdx.y, c = blockIdx.x;
     const int64_t base = (int64_t)g * bpg * 2 * C + c;
-    const double s1 = wave_sum_partials(ws, base, 2 * (int64_t)C, bpg);
-    const double s2 = wave_sum_partials(ws, base + C, 2 * (int64_t)C, bpg);
-    if ((threadIdx.x & 63) != 0) return;
+    const double s1 = block_sum_partials(ws, base, 2 * (int64_t)C, bpg, sm);
+    const double s2 = block_sum_partials(ws, base + C, 2 * (int64_t)C, bpg, sm);
+    if (threadIdx.x != 0) return;
     red[((int64_t)g * C + c) * 2 + 0] = (float)s1;
     red[((int64_t)g * C + c) * 2 + 1] = (float)s2;
     if (dgamma && g == 0) {
@@ -1016,7 +1027,7 @@ extern "C" int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t gro
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 0>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
                                                      (const T*)x, ld, M, (int)C, bpg, (float*)workspace));
     SEGK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)groups), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st,
                        (const float*)workspace, bpg, M, (int)C, eps, stats, running_mean, running_var, momentum);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
@@ -1071,7 +1082,7 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_partial_kernel<T>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
                                                      (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, bpg, part));
     SEGK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)((C + 3) / 4), (unsigned)groups), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st,
                        (const float*)part, bpg, (int)C, red, dgamma, dbeta, accumulate);
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
@@ -1136,7 +1147,7 @@ extern "C" int segk_norm_pool_bwd(int dtype, const void* dy, int64_t ld_dy, cons
                                                      (const T*)dpool, ld_dpool, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, stats, gamma,
                                                      beta, bpg, part));
     SEGK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)((C + 3) / 4), 1), dim3(kThreads), 0, st, (const float*)part, bpg, (int)C,
+    hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, 1), dim3(kThreads), 0, st, (const float*)part, bpg, (int)C,
                        red, dgamma, dbeta, accumulate);
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
@@ -1237,7 +1248,7 @@ extern "C" int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int6
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 1>), dim3(bpg, 1), dim3(kThreads), 0, st, (const T*)x, ld, P,
                                                      (int)C, bpg, (float*)workspace));
     SEGK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)((C + 3) / 4)), dim3(kThreads), 0, st,
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(kThreads), 0, st,
                        (const float*)workspace, bpg, (int)C, out, (flags >> 1) & 1);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;

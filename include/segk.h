@@ -125,7 +125,7 @@ int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, int taps, int
  *           models/unetplusplus.py:11,13) and -- called with the `wb` image on dy -- the
  *           data-gradient half of its backward; taps=1 gives a 1x1 convolution.
  * The input is the channel concatenation of up to two segments (x0 then x1; torch.cat at
- * models/unetvgg.py:99-103, models/unetplusplus.py:64-79); C0, C1 multiples of 8.
+ * models/unetvgg.py:99-103, models/unetplusplus.py:64-79); C0, C1, Cout and mask_channels multiples of 8.
  * flags bit0: ReLU epilogue; mask (optional, same dtype, ld_mask): output channels [0, mask_channels) are zeroed
  * where mask<=0: the ReLU backward of the producer(s) of those channels, fused into the data gradient.
  * flags bit1: accumulate into y (y += result) instead of overwriting.                             */
