@@ -796,8 +796,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                         }
 #pragma unroll
                         for (int i = 0; i < WTI; ++i)
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[i]),
-                                                                                  __builtin_bit_cast(bf16x8, fb), acc[t][i][j], 0, 0, 0);
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb),
+                                                                                  __builtin_bit_cast(bf16x8, fa[i]), acc[t][i][j], 0, 0, 0);
                     }
                 }
                 // advance to the next K-step: two tile rows; after the last one, to the start of the other stage
@@ -836,7 +836,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                         const int c = (wj * WTJ + j) * 16 + l15;
                         const float fb = *reinterpret_cast<const float*>(&s_x[hp * kRowBytes + ((((c >> 2) ^ wg_swz<T>(hx)) << 4) | ((c & 3) << 2))]);
 #pragma unroll
-                        for (int i = 0; i < WTI; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb, acc[t][i][j], 0, 0, 0);
+                        for (int i = 0; i < WTI; ++i) acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb, fa[i], acc[t][i][j], 0, 0, 0);
                     }
                 }
             }
@@ -847,7 +847,8 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         __syncthreads();
     }
 
-    // partial slab: slab[split][co][tap][ci]
+    // partial slab: slab[split][co][tap][ci].  The input-channel tile is the MFMA's row operand, so a lane holds four
+    // consecutive input channels of one output channel: one 16-byte store each.
     const int cin_tot = a.nch * KR;
     const int64_t co_tot = (int64_t)a.ncb * KR;
 #pragma unroll
@@ -856,12 +857,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         for (int i = 0; i < WTI; ++i)
 #pragma unroll
             for (int j = 0; j < WTJ; ++j) {
-                const int ci = chunk * KR + (wj * WTJ + j) * 16 + l15;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int co = cb * KR + (wi * WTI + i) * 16 + 4 * g + r;
-                    a.slab[(((int64_t)split * co_tot + co) * TAPS + t) * cin_tot + ci] = acc[t][i][j][r];
-                }
+                const int co = cb * KR + (wi * WTI + i) * 16 + l15;
+                const int ci = chunk * KR + (wj * WTJ + j) * 16 + 4 * g;
+                *reinterpret_cast<float4*>(&a.slab[(((int64_t)split * co_tot + co) * TAPS + t) * cin_tot + ci]) =
+                    make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
             }
 }
 
