@@ -21,6 +21,7 @@ for p in (ROOT, os.path.join(ROOT, "image-segmentation_amd")):
 
 import torch  # noqa: E402
 
+ALGO_CONV_GB_PER_STEP = 22.81  # every convolution operand (bf16 activations of fwd, dgrad, wgrad) moved once, batch 32
 GFLOP_PER_SLICE = 509.72       # conv fwd+dgrad+wgrad of UNetVgg(out_classes=4) at 384x384, 2 FLOP/MAC, no dgrad on conv1.0
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense MI355X matrix peaks
 
@@ -167,8 +168,16 @@ def main():
             conv_ms = (fwd + wg) / args.steps
             achieved = gflop * args.batch / conv_ms        # GFLOP / ms = TFLOP/s
             peak = MFMA_PEAK_TFLOPS[args.dtype]
+            # HBM bytes of the same launches (one step) from the committed PMC passes of this workload; null for other workloads
+            traffic = None
+            tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            if args.model == "unetvgg" and args.dtype == "bf16" and args.batch == 32 and args.side == 384 and os.path.exists(tfile):
+                with open(tfile) as f:
+                    traffic = json.load(f).get("conv_mfma_kernels_hbm_bytes_per_step")
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(achieved / peak, 4), "traffic": None,
+                               "frac": round(achieved / peak, 4), "traffic": traffic,
+                               "traffic_note": "HBM bytes per step of these launches (rocprofv3 PMC, profiles/r01_hbm_traffic.json); "
+                                               f"algorithmic minimum {ALGO_CONV_GB_PER_STEP} GB",
                                "kernel": "conv_fwd_kernel + conv_wgrad_kernel (all MFMA convolution launches of a step)",
                                "launches_per_step": len(timer) // args.steps, "conv_ms_per_step": round(conv_ms, 3),
                                "fwd_dgrad_ms": round(fwd / args.steps, 3), "wgrad_ms": round(wg / args.steps, 3),
