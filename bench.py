@@ -154,7 +154,8 @@ def main():
         ms = 1e3 * elapsed / args.steps
         value = world * args.batch * args.steps / elapsed
         out = {
-            "metric": "train slices/sec (fwd+bwd+loss) UNet-VGG 384x384", "value": round(value, 2), "unit": "slices/s",
+            "metric": "train slices/sec (fwd+bwd+loss) " + {"unetvgg": "UNet-VGG", "unetvgg_convtrans": "UNet-VGG (transposed-conv decoder)",
+                                                              "unetpp": "UNet++"}[args.model] + f" {args.side}x{args.side}", "value": round(value, 2), "unit": "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.model} {args.side}x{args.side}, {n_classes} classes, {args.batch} slices/GPU, "
@@ -176,8 +177,8 @@ def main():
                     traffic = json.load(f).get("conv_mfma_kernels_hbm_bytes_per_step")
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,
-                               "traffic_note": "HBM bytes per step of these launches (rocprofv3 PMC, profiles/r01_hbm_traffic.json); "
-                                               f"algorithmic minimum {ALGO_CONV_GB_PER_STEP} GB",
+                               "traffic_note": ("HBM bytes per step of these launches (rocprofv3 PMC, profiles/r01_hbm_traffic.json); "
+                                                f"algorithmic minimum {ALGO_CONV_GB_PER_STEP} GB") if traffic else None,
                                "kernel": "conv_fwd_kernel + conv_wgrad_kernel (all MFMA convolution launches of a step)",
                                "launches_per_step": len(timer) // args.steps, "conv_ms_per_step": round(conv_ms, 3),
                                "fwd_dgrad_ms": round(fwd / args.steps, 3), "wgrad_ms": round(wg / args.steps, 3),

@@ -627,7 +627,7 @@ struct WgradArgs {
 };
 
 template <typename T> __device__ __forceinline__ int wg_swz(int pix);
-template <> __device__ __forceinline__ int wg_swz<bf16>(int pix) { return (((pix >> 1) & 1) << 1) | (((pix >> 3) & 1) << 2); }
+template <> __device__ __forceinline__ int wg_swz<bf16>(int pix) { return ((pix >> 1) & 3) << 1; }
 template <> __device__ __forceinline__ int wg_swz<float>(int pix) { return (pix & 1) << 2; }
 
 // TDI / TDJ: 16-wide tiles of the output-channel / input-channel side that hold real channels (a K-row has KR/16);
@@ -727,33 +727,31 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         }
     };
 
-    // bf16 operand reads (transposing 8-byte LDS reads): lane (li = lane&15, g) with q = li>>2, p = li&3 supplies the
-    // address of pixel (row g>>1, column 8*(g&1) + q (+4 for the second half)) of a 32-pixel K-step and of 8-byte unit
-    // (tile*4 + p); it receives channel tile*16 + li.  LDS byte addresses for stage 0: the output-gradient tile, and
-    // the input halo per column variant (kx for 3x3 taps; the whole tap for the 2x2 phase taps, whose offsets are
-    // run-time values); the halo swizzle depends on the halo COLUMN only, so taps that differ in ky and successive
-    // K-steps reuse the same register with another immediate offset.
+    // bf16 operand reads (transposing 8-byte LDS reads).  A K-step is 32 pixels = two tile rows; half h of a fragment
+    // is row h: lane (li = lane&15, g) with q = li>>2, p = li&3 supplies the address of pixel (row h, column 4g + q)
+    // and of 8-byte unit (tile*4 + p), and receives channel tile*16 + li for K indices 8g + 4h .. +3.  Both operands
+    // use this pixel <-> K map.  One read therefore covers one pixel row, and the halo rows of a K-step are shared by
+    // the taps that differ in ky: four row reads serve ky = 0, 1, 2.  The swizzle depends on the COLUMN only (eight
+    // consecutive columns hit eight different 32-byte bank groups), so rows, taps and K-steps differ from the per-lane
+    // base by immediate offsets.  LDS byte addresses for stage 0:
     constexpr int NV = TAPS == 9 ? 3 : (TAPS == 4 ? 4 : 1);
-    unsigned adrA[WTI][2], adrB[NV][WTJ][2];
+    unsigned adrA[WTI], adrB[NV][WTJ];
     if constexpr (kBf16) {
-        const int q = l15 >> 2, p = l15 & 3, prow = g >> 1, pcol = 8 * (g & 1) + q;
+        const int q = l15 >> 2, p = l15 & 3, pcol = 4 * g + q;
 #pragma unroll
-        for (int i = 0; i < WTI; ++i)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int pix = prow * kTW + pcol + 4 * h, u = (wi * WTI + i) * 4 + p;
-                adrA[i][h] = lds0 + XBYTES + pix * kRowBytes + (((u >> 1) ^ wg_swz<T>(pix)) << 4) + (u & 1) * 8;
-            }
+        for (int i = 0; i < WTI; ++i) {
+            const int u = (wi * WTI + i) * 4 + p;
+            adrA[i] = lds0 + XBYTES + pcol * kRowBytes + (((u >> 1) ^ wg_swz<T>(pcol)) << 4) + (u & 1) * 8;
+        }
 #pragma unroll
         for (int v = 0; v < NV; ++v)
 #pragma unroll
-            for (int j = 0; j < WTJ; ++j)
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int kx = TAPS == 9 ? v : (TAPS == 4 ? a.tkx[v] : 0), kyr = TAPS == 4 ? a.tky[v] : 0;
-                    const int hx = pcol + 4 * h + kx, hp = (prow + kyr) * HW_ + hx, u = (wj * WTJ + j) * 4 + p;
-                    adrB[v][j][h] = lds0 + hp * kRowBytes + (((u >> 1) ^ wg_swz<T>(hx)) << 4) + (u & 1) * 8;
-                }
+            for (int j = 0; j < WTJ; ++j) {
+                // column variant: kx for 3x3 taps; the whole tap (run-time offsets) for the 2x2 phase taps
+                const int kx = TAPS == 9 ? v : (TAPS == 4 ? a.tkx[v] : 0), kyr = TAPS == 4 ? a.tky[v] : 0;
+                const int hx = pcol + kx, hp = kyr * HW_ + hx, u = (wj * WTJ + j) * 4 + p;
+                adrB[v][j] = lds0 + hp * kRowBytes + (((u >> 1) ^ wg_swz<T>(hx)) << 4) + (u & 1) * 8;
+            }
     }
 
     if (t_lo < t_hi) stage(t_lo, 0);
@@ -774,31 +772,45 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
 #pragma unroll 1
             for (int kk = 0; kk < TPIX / 32; ++kk) {
+                auto row_read = [&](unsigned base, int row, int row_pixels) {
+                    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((lds_cptr)(size_t)base + row * row_pixels * kRowBytes));
+                };
+                auto join = [](const s16x4& lo, const s16x4& hi) {
+                    s16x8 f;
+                    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+                    return f;
+                };
                 s16x8 fa[WTI];
 #pragma unroll
-                for (int i = 0; i < WTI; ++i)
+                for (int i = 0; i < WTI; ++i) fa[i] = join(row_read(adrA[i], 0, kTW), row_read(adrA[i], 1, kTW));
+                if constexpr (TAPS == 9) {
 #pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((lds_cptr)(size_t)adrA[i][h]));
-                        fa[i][4 * h + 0] = r[0]; fa[i][4 * h + 1] = r[1]; fa[i][4 * h + 2] = r[2]; fa[i][4 * h + 3] = r[3];
-                    }
+                    for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int v = TAPS == 9 ? t % 3 : (TAPS == 4 ? t : 0), ky = TAPS == 9 ? t / 3 : 0;
+                        for (int j = 0; j < WTJ; ++j) {
+                            s16x4 rf[4];
 #pragma unroll
-                    for (int j = 0; j < WTJ; ++j) {
-                        s16x8 fb;
+                            for (int r = 0; r < 4; ++r) rf[r] = row_read(adrB[kx][j], r, HW_);
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            const s16x4 r = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                                (lds_s16x4)((lds_cptr)(size_t)adrB[v][j][h] + ky * HW_ * kRowBytes));
-                            fb[4 * h + 0] = r[0]; fb[4 * h + 1] = r[1]; fb[4 * h + 2] = r[2]; fb[4 * h + 3] = r[3];
+                            for (int ky = 0; ky < 3; ++ky) {
+                                const s16x8 fb = join(rf[ky], rf[ky + 1]);
+#pragma unroll
+                                for (int i = 0; i < WTI; ++i)
+                                    acc[ky * 3 + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(bf16x8, fb), __builtin_bit_cast(bf16x8, fa[i]), acc[ky * 3 + kx][i][j], 0, 0, 0);
+                            }
                         }
+                } else {
 #pragma unroll
-                        for (int i = 0; i < WTI; ++i)
-                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb),
-                                                                                  __builtin_bit_cast(bf16x8, fa[i]), acc[t][i][j], 0, 0, 0);
-                    }
+                    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                        for (int j = 0; j < WTJ; ++j) {
+                            const s16x8 fb = join(row_read(adrB[t][j], 0, HW_), row_read(adrB[t][j], 1, HW_));
+#pragma unroll
+                            for (int i = 0; i < WTI; ++i)
+                                acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb),
+                                                                                      __builtin_bit_cast(bf16x8, fa[i]), acc[t][i][j], 0, 0, 0);
+                        }
                 }
                 // advance to the next K-step: two tile rows; after the last one, to the start of the other stage
                 const bool last = kk == TPIX / 32 - 1;
@@ -806,15 +818,11 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                 const int stepA = last ? back - (TPIX / 32 - 1) * 32 * kRowBytes : 32 * kRowBytes;
                 const int stepB = last ? back - (TPIX / 32 - 1) * 2 * HW_ * kRowBytes : 2 * HW_ * kRowBytes;
 #pragma unroll
-                for (int i = 0; i < WTI; ++i)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) adrA[i][h] += stepA;
+                for (int i = 0; i < WTI; ++i) adrA[i] += stepA;
 #pragma unroll
                 for (int v = 0; v < NV; ++v)
 #pragma unroll
-                    for (int j = 0; j < WTJ; ++j)
-#pragma unroll
-                        for (int h = 0; h < 2; ++h) adrB[v][j][h] += stepB;
+                    for (int j = 0; j < WTJ; ++j) adrB[v][j] += stepB;
             }
         } else {
             // fp32: K-step = 4 pixels; lane (m = lane&15, k = lane>>4) reads one element of each operand.
