@@ -110,22 +110,23 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 }
 
 template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES>
-__global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES * WCO_WAVES)) void conv_fwd_kernel(const ConvArgs a) {
+    constexpr int NT = 64 * WPX_WAVES * WCO_WAVES;   // threads: 4 waves (two workgroups per CU) or 8 waves (one)
     constexpr int PAD = TAPS == 1 ? 0 : 1;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_;
     constexpr int HSLOTS = HPIX * 8;
-    constexpr int HL = (HSLOTS + TAPS * kConvThreads - 1) / (TAPS * kConvThreads);   // halo transfers / thread / step
-    constexpr int WL = BN * 8 / kConvThreads;                                        // weight transfers / thread / step
-    static_assert(BN * 8 % kConvThreads == 0, "weight tile must split evenly");
+    constexpr int HL = (HSLOTS + TAPS * NT - 1) / (TAPS * NT);   // halo transfers / thread / step
+    constexpr int WL = BN * 8 / NT;                                        // weight transfers / thread / step
+    static_assert(BN * 8 % NT == 0, "weight tile must split evenly");
     constexpr int WCO = BN / WCO_WAVES, WPX = TH * kTW / WPX_WAVES;
     constexpr int NI = WCO / 16, NJ = WPX / 16;
-    static_assert(WPX_WAVES * WCO_WAVES == 4 && NI >= 1 && NJ >= 1, "bad wave layout");
+    static_assert((WPX_WAVES * WCO_WAVES == 4 || WPX_WAVES * WCO_WAVES == 8) && NI >= 1 && NJ >= 1, "bad wave layout");
     constexpr int EPS = 16 / (int)sizeof(T);   // elements per 16-byte slot
     // the halo of a K-row is moved in HPARTS parts of HL transfers per thread, one part per tap; the buffer is padded
     // to whole parts so that every wave issues every transfer (the counted DMA wait relies on equal counts)
-    constexpr int HPARTS = (HSLOTS + HL * kConvThreads - 1) / (HL * kConvThreads);
+    constexpr int HPARTS = (HSLOTS + HL * NT - 1) / (HL * NT);
     static_assert(HPARTS <= TAPS, "halo parts must fit the taps of a K-row");
-    constexpr int HBYTES = HPARTS * HL * kConvThreads * 16, WBYTES = BN * kRowBytes;
+    constexpr int HBYTES = HPARTS * HL * NT * 16, WBYTES = BN * kRowBytes;
 
     // one LDS object: [halo 0 | halo 1 | weights 0 | weights 1]
     __shared__ __attribute__((aligned(16))) char smem[2 * HBYTES + 2 * WBYTES];
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(const ConvArg
     int hinfo[HPARTS * HL];
 #pragma unroll
     for (int p = 0; p < HPARTS * HL; ++p) {
-        const int q = p * kConvThreads + tid;
+        const int q = p * NT + tid;
         const int pix = q >> 3, sl = (q & 7) ^ (pix & 7);
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(const ConvArg
             const int ch = ch0 + (info & 7) * EPS;
             const bool ok = info >= 0 && ch < cmax;
             const char* src = ok ? base + ((int64_t)(info >> 3) * ld + ch) * (int64_t)sizeof(T) : reinterpret_cast<const char*>(&kZeroSlot);
-            glds16_hidden(src, lds0 + buf * HBYTES + ((part * HL + k) * kConvThreads + wave * 64) * 16);
+            glds16_hidden(src, lds0 + buf * HBYTES + ((part * HL + k) * NT + wave * 64) * 16);
         }
     };
     const char* const wsrc0 = a.w + (int64_t)cb * BN * kRowBytes + (int64_t)tid * 16;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_fwd_kernel(const ConvArg
         const char* src = wsrc0 + (int64_t)step * a.cout_pad * kRowBytes;
 #pragma unroll
         for (int k = 0; k < WL; ++k)
-            glds16_hidden(src + k * kConvThreads * 16, lds0 + 2 * HBYTES + buf * WBYTES + (k * kConvThreads + wave * 64) * 16);
+            glds16_hidden(src + k * NT * 16, lds0 + 2 * HBYTES + buf * WBYTES + (k * NT + wave * 64) * 16);
     };
 
     const int nsteps = a.nch * TAPS;
@@ -912,6 +913,8 @@ static inline int pick_bn(int64_t cout_pad) {
 template <typename T, int TAPS>
 static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
     const unsigned grid = (unsigned)((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn));
+    // (a 16x16-pixel tile on 8 waves, <T, TAPS, 16, 128, 4, 2>, halves the weight traffic into LDS per FLOP but measured
+    // 2-5 % slower on the UNet-VGG layers: one 8-wave barrier domain per CU instead of two independent 4-wave ones)
     if (bn == 128)
         hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 128, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else if (bn == 96)

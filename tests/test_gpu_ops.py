@@ -94,6 +94,7 @@ THIN_CASES = [
     (2, 200, 328, 64, 0, 128),    # ragged borders, two channel blocks
     (2, 208, 320, 32, 64, 32),    # two segments (half K-row + K-row), 32-channel block; data gradient: 3 blocks of 32
     (2, 256, 272, 128, 0, 32),    # two K-rows
+    (4, 128, 128, 128, 0, 256),   # more workgroups than fit the device at once (several resident rounds)
 ]
 
 
