@@ -214,47 +214,66 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES *
         const int nks = rc > KRow<T>::kElems / 2 ? 2 : 1;
         const bool next_chunk = chunk + 1 < a.nch;
         const char* hb = s_halo0 + (chunk & 1) * HBYTES;
+        auto tap_ky = [&](int tap) { return TAPS == 9 ? tap / 3 : (TAPS == 4 ? a.tky[tap] : 0); };
+        auto tap_kx = [&](int tap) { return TAPS == 9 ? tap % 3 : (TAPS == 4 ? a.tkx[tap] : 0); };
+        auto load_b = [&](int tap, int ks, Slot (&fb)[NJ]) {
+            const int slot = ks * 4 + g;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int hp = hp_l + (j + tap_ky(tap)) * HW_ + tap_kx(tap);
+                fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
+            }
+        };
+        auto load_a = [&](const char* wb, int ks, Slot (&fa)[NI]) {
+            const int slot = ks * 4 + g;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int co = co_l + i * 16;
+                fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
+            }
+        };
+        // Pixel fragments of a tap's first k-substep are read BEFORE the barrier that ends the previous tap (the halo
+        // buffer does not change within a K-row), so only the weight fragments wait for that barrier.
+        Slot fb0[NJ];
+        load_b(0, 0, fb0);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int step = chunk * TAPS + tap;
-            // DMA for later steps goes out first: the weights of the NEXT (K-row, tap) into the other weight buffer,
-            // then one part of the NEXT K-row's halo into the other halo buffer.  Issue order matters: the wait at
-            // the end of the step leaves the (younger) halo transfers in flight, so their HBM latency is spread
-            // over the remaining taps of the K-row instead of being paid every step.
+            const char* wb = s_w0 + (step & 1) * WBYTES;
+            Slot fa0[NI];
+            load_a(wb, 0, fa0);
+            __builtin_amdgcn_sched_barrier(0);
+            // DMA for later steps goes out while those reads are in flight: the weights of the NEXT (K-row, tap) into the
+            // other weight buffer, then one part of the NEXT K-row's halo into the other halo buffer.  Issue order
+            // matters: the wait at the end of the step leaves the (younger) halo transfers in flight, so their HBM
+            // latency is spread over the remaining taps of the K-row instead of being paid every step.
             if (step + 1 < nsteps) stage_w(step + 1, (step + 1) & 1);
             const bool halo_now = tap < HPARTS && next_chunk;
             if (halo_now) stage_halo_part(chunk + 1, (chunk + 1) & 1, tap);
-            const char* wb = s_w0 + (step & 1) * WBYTES;
-            constexpr int kyx = 0;
-            (void)kyx;
-            const int ky = TAPS == 9 ? tap / 3 : (TAPS == 4 ? a.tky[tap] : 0), kx = TAPS == 9 ? tap % 3 : (TAPS == 4 ? a.tkx[tap] : 0);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                if (ks >= nks) break;
-                const int slot = ks * 4 + g;
-                Slot fa[NI], fb[NJ];
+            for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int co = co_l + i * 16;
-                    fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + ((slot ^ (co & 7)) << 4));
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int hp = hp_l + (j + ky) * HW_ + kx;
-                    fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
-                }
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa0[i], fb0[j], acc[i][j]);
+            if (nks == 2) {
+                Slot fa1[NI], fb1[NJ];
+                load_a(wb, 1, fa1);
+                load_b(tap, 1, fb1);
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
-                    for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+                    for (int j = 0; j < NJ; ++j) Mma<T>::run(fa1[i], fb1[j], acc[i][j]);
             }
-            // keep the MFMA cluster in front of the DMA wait (register-only instructions may otherwise be moved
-            // across it).  Wait for everything but this step's halo transfers (the last tap of a K-row waits for
-            // all: the next K-row reads that halo), then: next weight buffer complete, current buffers free.
+            if (tap + 1 < TAPS) load_b(tap + 1, 0, fb0);
+            // keep the MFMA cluster and the prefetch in front of the DMA wait.  Wait for everything but this step's halo
+            // transfers (the last tap of a K-row waits for all: the next K-row reads that halo), then: next weight
+            // buffer complete, current buffers free.  A bare s_barrier: the LDS reads in flight across it are of a buffer
+            // that nobody overwrites before the NEXT barrier, and DMA completion is tracked by the counted waits.
             __builtin_amdgcn_sched_barrier(0);
             if (tap == TAPS - 1 || !halo_now) dma_wait_all();
             else dma_wait_but<HL>();
-            __syncthreads();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
