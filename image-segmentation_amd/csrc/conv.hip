@@ -790,27 +790,44 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
             // compile-time offset, so the loop issues no address arithmetic between the MFMAs.
             typedef __attribute__((address_space(3))) char* lds_cptr;
             typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-#pragma unroll 1
-            for (int kk = 0; kk < TPIX / 32; ++kk) {
-                auto row_read = [&](unsigned base, int row, int row_pixels) {
-                    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((lds_cptr)(size_t)base + row * row_pixels * kRowBytes));
-                };
-                auto join = [](const s16x4& lo, const s16x4& hi) {
-                    s16x8 f;
-                    f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
-                    return f;
-                };
-                s16x8 fa[WTI];
+            auto row_read = [&](unsigned base, int row, int row_pixels) {
+                return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((lds_cptr)(size_t)base + row * row_pixels * kRowBytes));
+            };
+            auto join = [](const s16x4& lo, const s16x4& hi) {
+                s16x8 f;
+                f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+                return f;
+            };
+            // fragments that open a K-step are read while the previous K-step's last MFMAs issue (software pipeline
+            // across K-steps); only the first K-step of a tile, whose stage has just been published, reads them up front
+            s16x8 fa[WTI];
+            s16x4 rf0[4];
 #pragma unroll
-                for (int i = 0; i < WTI; ++i) fa[i] = join(row_read(adrA[i], 0, kTW), row_read(adrA[i], 1, kTW));
+            for (int i = 0; i < WTI; ++i) fa[i] = join(row_read(adrA[i], 0, kTW), row_read(adrA[i], 1, kTW));
+            if constexpr (TAPS == 9) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rf0[r] = row_read(adrB[0][0], r, HW_);
+            }
+#pragma unroll 2
+            for (int kk = 0; kk < TPIX / 32; ++kk) {
+                const bool more = kk + 1 < TPIX / 32;
                 if constexpr (TAPS == 9) {
+                    s16x8 fan[WTI];
+                    s16x4 rfn[4];
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                         for (int j = 0; j < WTJ; ++j) {
                             s16x4 rf[4];
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) rf[r] = row_read(adrB[kx][j], r, HW_);
+                            for (int r = 0; r < 4; ++r) rf[r] = (kx == 0 && j == 0) ? rf0[r] : row_read(adrB[kx][j], r, HW_);
+                            if (kx == 2 && j == WTJ - 1 && more) {
+                                // next K-step = two rows further down both images
+#pragma unroll
+                                for (int i = 0; i < WTI; ++i) fan[i] = join(row_read(adrA[i], 2, kTW), row_read(adrA[i], 3, kTW));
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) rfn[r] = row_read(adrB[0][0], r + 2, HW_);
+                            }
 #pragma unroll
                             for (int ky = 0; ky < 3; ++ky) {
                                 const s16x8 fb = join(rf[ky], rf[ky + 1]);
@@ -820,6 +837,12 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                                         __builtin_bit_cast(bf16x8, fb), __builtin_bit_cast(bf16x8, fa[i]), acc[ky * 3 + kx][i][j], 0, 0, 0);
                             }
                         }
+                    if (more) {
+#pragma unroll
+                        for (int i = 0; i < WTI; ++i) fa[i] = fan[i];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rf0[r] = rfn[r];
+                    }
                 } else {
 #pragma unroll
                     for (int t = 0; t < TAPS; ++t)
@@ -831,6 +854,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
                                 acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb),
                                                                                       __builtin_bit_cast(bf16x8, fa[i]), acc[t][i][j], 0, 0, 0);
                         }
+                    if (more) {
+#pragma unroll
+                        for (int i = 0; i < WTI; ++i) fa[i] = join(row_read(adrA[i], 2, kTW), row_read(adrA[i], 3, kTW));
+                    }
                 }
                 // advance to the next K-step: two tile rows; after the last one, to the start of the other stage
                 const bool last = kk == TPIX / 32 - 1;
