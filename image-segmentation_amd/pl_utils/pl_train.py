@@ -1,0 +1,39 @@
+"""`train_model` / `test_model`: the lightning branch of the reference's `train_general`
+(/root/reference/pl_utils/pl_train.py:6-44, /root/reference/pl_utils/pl_test.py:3-26)."""
+import os
+import shutil
+
+import pytorch_lightning as pl
+import torch
+from pytorch_lightning.callbacks import ModelCheckpoint
+
+
+def train_model(lightn_model, checkpoint_path, del_pre_files=True, device=None, num_epochs=11):
+    """Empty `checkpoint_path` (when asked), train for `num_epochs`, keep the checkpoint with the best `val_acc`."""
+    os.makedirs(checkpoint_path, exist_ok=True)
+    if del_pre_files:
+        for name in os.listdir(checkpoint_path):
+            path = os.path.join(checkpoint_path, name)
+            if os.path.isfile(path) or os.path.islink(path):
+                os.unlink(path)
+            elif os.path.isdir(path):
+                shutil.rmtree(path)
+    checkpoint_callback = ModelCheckpoint(monitor="val_acc", filepath=checkpoint_path, mode="max")
+    num_gpus = 1 if (device is not None and torch.device(device).type == 'cuda') else None
+    trainer = pl.Trainer(gpus=num_gpus, max_epochs=num_epochs, default_root_dir=checkpoint_path,
+                         checkpoint_callback=checkpoint_callback, val_check_interval=1)
+    trainer.fit(lightn_model)
+    return trainer
+
+
+def test_model(model, checkpoint_path, trainer):
+    """Reload the saved best checkpoint (first file with "epoch" in its name) and run the test loop."""
+    if trainer is None:
+        return None
+    for name in sorted(os.listdir(checkpoint_path)):
+        path = os.path.join(checkpoint_path, name)
+        if os.path.isfile(path) and "epoch" in name:
+            checkpoint = torch.load(path, map_location="cpu", weights_only=True)
+            model.load_state_dict(checkpoint['state_dict'])
+            break
+    return trainer.test(model)

@@ -2,9 +2,9 @@
 (/root/reference/detect_region/common.py:18-116, /root/reference/perlosstrain/common.py:17-108; call site
 /root/reference/train_midlslice.py:30-33).  Same signature and defaults as the detect_region variant.
 
-Differences, on purpose: the pytorch-lightning branch (`is_naive_train=False`) needs the third-party trainer, which
-is not part of this build, so that branch raises; figure export after the test pass (matplotlib) is replaced by the
-returned metrics (`model.segk_metrics`).  The default network is `UNetVgg()`.
+Differences, on purpose: figure export after the test pass (matplotlib) is replaced by the returned metrics
+(`model.segk_metrics`); the default network is `UNetVgg()`.  The pytorch-lightning branch (`is_naive_train=False`)
+runs on the installed pytorch_lightning, or on the minimal stand-in of segk_compat.lightning when that is absent.
 """
 import torch
 from torch.utils.data import DataLoader
@@ -36,7 +36,17 @@ def train_general(dataset, out_path, expt_name="", val_set_perc=0.15, test_set_p
     if val_acc_func is None:
         val_acc_func = dice_coefficient
     if not is_naive_train:
-        raise NotImplementedError("the pytorch-lightning trainer branch is not part of this build: pass is_naive_train=True")
+        from pl_utils.pl_mod import SegmModelPL
+        from pl_utils.pl_train import test_model, train_model
+        lightn_mod = SegmModelPL(net_model, train_set, val_set, test_set, batch_size, test_batch_size, loss_criterion=loss_criterion,
+                                 val_acc_func=val_acc_func, lr=lr, experiment_name=expt_name).to(device)
+        trainer = train_model(lightn_mod, out_path, del_pre_files=True, device=device, num_epochs=num_epochs)
+        metrics = dict(trainer.callback_metrics)
+        if test_set_perc and test_set is not None and len(test_set):
+            test_model(lightn_mod, out_path, trainer)
+            metrics.update(trainer.callback_metrics)
+        lightn_mod.segk_metrics = metrics
+        return lightn_mod
     net_model = net_model.to(device)
     metrics = naive_train(train_set, val_set, net_model, loss_criterion, val_acc_func, num_epochs, batch_size, device, out_path,
                           kwargs, experiment_name=expt_name, valid_after=valid_after, lr=lr, use_saved=use_saved)

@@ -35,11 +35,23 @@ def test_train_general_cpu(tmp_path):
     UNetVgg(out_classes=4).load_state_dict(state["state_dict"], strict=True)
 
 
-def test_lightning_branch_raises(tmp_path):
+def test_lightning_branch_cpu(tmp_path):
+    """is_naive_train=False: SegmModelPL + train_model/test_model on the lightning stand-in (or the real package)."""
     from data_read.synthetic import SyntheticSlices
+    from loss.dice import dice_coefficient, dice_loss_sq
+    from models.unetvgg import UNetVgg
+    from oracle.ref_models import hash_init_
     from train_helper.common import train_general
-    with pytest.raises(NotImplementedError):
-        train_general(SyntheticSlices(num_img=8, side=32), str(tmp_path), is_naive_train=False)
+    torch.manual_seed(20)
+    mod = train_general(SyntheticSlices(num_img=16, side=64), str(tmp_path), expt_name="pl", val_set_perc=0.25, test_set_perc=0.125,
+                        device=torch.device("cpu"), num_epochs=2, is_naive_train=False, net_model=hash_init_(UNetVgg(out_classes=4)),
+                        batch_size=4, test_batch_size=2, loss_criterion=[dice_loss_sq], val_acc_func=dice_coefficient, lr=1e-3)
+    m = mod.segk_metrics
+    assert {"loss", "val_loss", "val_acc", "test_loss", "test_acc"} <= set(m)
+    names = [n for n in os.listdir(tmp_path) if "epoch" in n]
+    assert len(names) == 1
+    state = torch.load(os.path.join(tmp_path, names[0]), weights_only=True)
+    assert all(k.startswith("model.") for k in state["state_dict"])      # keys of the wrapping module, as in the reference
 
 
 def test_mid_slice_stand_in():
