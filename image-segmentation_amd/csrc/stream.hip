@@ -948,6 +948,19 @@ __global__ __launch_bounds__(kThreads) void adam_kernel(float* __restrict__ p, c
     }
 }
 
+// Blocks along x for the row-strided streaming kernels: every thread should see >= 16 pixel rows so that its per-channel
+// constants (statistics, affine parameters: 32 scalar loads) amortise, but the launch keeps >= ~1024 blocks when
+// there is at least one row per thread for them.
+static int64_t stream_blocks(int64_t M, int rows, int64_t groups) {
+    const int64_t per_row = (M + rows - 1) / rows;
+    int64_t gx = (per_row + 15) / 16;
+    const int64_t floor_blocks = (1024 + groups - 1) / groups;
+    if (gx < floor_blocks) gx = per_row < floor_blocks ? per_row : floor_blocks;
+    const int64_t cap = (8192 + groups - 1) / groups;
+    if (gx > cap) gx = cap;
+    return gx < 1 ? 1 : gx;
+}
+
 static int stats_bpg(int64_t groups, int64_t M, int64_t C) {
     // ~16 pixel rows of work per thread at least; cap total blocks near 4096
     const int64_t rows = kThreads / (C / 8);
@@ -1051,9 +1064,7 @@ extern "C" int segk_norm_apply(int dtype, const void* x, int64_t ldx, int64_t gr
     SEGK_REQUIRE(stats && groups > 0 && groups < 65536 && M > 0, SEGK_EINVAL, "norm_apply: bad arguments");
     SEGK_HIP(use_device(dev));
     const int rows = kThreads / (int)(C / 8);
-    int64_t gx = (M + rows - 1) / rows;
-    const int64_t cap = (8192 + groups - 1) / groups;
-    if (gx > cap) gx = cap;
+    const int64_t gx = stream_blocks(M, rows, groups);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_apply_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)x, ldx, M, (int)C, stats, gamma, beta, flags & 1,
                                                      (T*)y, ldy));
@@ -1086,9 +1097,7 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
                        (const float*)part, bpg, (int)C, red, dgamma, dbeta, accumulate);
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
-    int64_t gx = (M + rows - 1) / rows;
-    const int64_t cap = (8192 + groups - 1) / groups;
-    if (gx > cap) gx = cap;
+    const int64_t gx = stream_blocks(M, rows, groups);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0, st,
                                                      (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, frozen,
                                                      (const float*)red, (T*)dx, ld_dx));
@@ -1114,8 +1123,7 @@ extern "C" int segk_norm_pool_apply(int dtype, const void* x, int64_t ldx, int64
     SEGK_HIP(use_device(dev));
     const int64_t Q = N * (H / 2) * (W / 2);
     const int rows = kThreads / (int)(C / 8);
-    int64_t gx = (Q + rows - 1) / rows;
-    if (gx > 8192) gx = 8192;
+    const int64_t gx = stream_blocks(Q, rows, 1);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_apply_kernel<T>), dim3((unsigned)gx), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, stats, gamma, beta,
                                                      (T*)y, ldy, (T*)pool, ld_pool));
@@ -1151,8 +1159,7 @@ extern "C" int segk_norm_pool_bwd(int dtype, const void* dy, int64_t ld_dy, cons
                        red, dgamma, dbeta, accumulate);
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
-    int64_t gx = (Q + rows - 1) / rows;
-    if (gx > 8192) gx = 8192;
+    const int64_t gx = stream_blocks(Q, rows, 1);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_bwd_dx_kernel<T>), dim3((unsigned)gx), dim3(kThreads), 0, st, (const T*)dy,
                                                      ld_dy, (const T*)dpool, ld_dpool, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, M, stats,
                                                      gamma, beta, frozen, (const float*)red, (T*)dx, ld_dx));

@@ -46,3 +46,14 @@ for H, C, ld in POOLS:
     if "pool_bwd" in which:
         t = timeit(lambda: ops.maxpool_bwd(x, dp, dxx, accumulate=True)); line += f" bwd(acc) {t:7.1f} us {3.25*sz/t:5.2f} TB/s |"
     print(line, flush=True)
+if "norm" in which:
+    for H, C in [(384, 64), (192, 128), (96, 256), (48, 512)]:
+        x = act(H, C); dy = act(H, C); out = act(H, C); dx = act(H, C)
+        stats = torch.empty(2 * C, device="cuda"); g = torch.ones(C, device="cuda"); b = torch.zeros(C, device="cuda")
+        dg = torch.empty(C, device="cuda"); db = torch.empty(C, device="cuda")
+        sz = N * H * H * C * 2 / 1e6
+        ops.norm_stats(x, 1, 1e-5, stats)
+        t1 = timeit(lambda: ops.norm_stats(x, 1, 1e-5, stats))
+        t2 = timeit(lambda: ops.norm_apply(x, 1, stats, g, b, True, out))
+        t3 = timeit(lambda: ops.norm_bwd(dy, x, 1, stats, g, b, True, dx, dgamma=dg, dbeta=db))
+        print(f"norm {H:3d} C={C:3d} | stats {t1:6.1f} us {sz/t1:5.2f} TB/s | apply {t2:6.1f} us {2*sz/t2:5.2f} TB/s | bwd {t3:6.1f} us {5*sz/t3:5.2f} TB/s |", flush=True)
