@@ -920,26 +920,56 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 }
 
 // dw[co][ci][tap] (OIHW) (+)= sum_splits slab[s][co][tap][ci]
+// P lanes share one output: lane = p * (64/P) + c handles output (wave * 64/P + c) and adds splits p, p+P, ...; a
+// butterfly over p finishes the sum (fixed order: deterministic).  P = 8 for the layers with few outputs and hundreds
+// of splits (a serial chain of 512 loads per thread otherwise), P = 1 where every thread has only a few splits.
+template <int P>
 __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int64_t co_tot,
                                                                          int taps, int cin_tot, int cout_real, int cin_real,
                                                                          int seg0, int k0_pad, float* __restrict__ dw,
                                                                          int accumulate, int ct_cout, int ct_k0, int ct_k1,
                                                                          int ct_k2, int ct_k3) {
+    constexpr int OPW = 64 / P;   // outputs per wavefront
     const int64_t total = (int64_t)cout_real * cin_real * taps;
-    for (int64_t i = (int64_t)blockIdx.x * kConvThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kConvThreads) {
-        // iterate with ci fastest so that slab reads are coalesced
-        const int ci = (int)(i % cin_real);
-        int64_t r = i / cin_real;
+    const int lane = threadIdx.x & 63, p = lane / OPW, c = lane % OPW;
+    const int64_t waves = (int64_t)gridDim.x * (kConvThreads / 64);
+    for (int64_t w = (int64_t)blockIdx.x * (kConvThreads / 64) + (threadIdx.x >> 6); w * OPW < total; w += waves) {
+        const int64_t i = w * OPW + c;
+        const bool live = i < total;
+        // ci fastest so that slab reads are coalesced
+        const int ci = live ? (int)(i % cin_real) : 0;
+        const int64_t r = live ? i / cin_real : 0;
         const int t = (int)(r % taps);
         const int co = (int)(r / taps);
         const int kc = ci < seg0 ? ci : k0_pad + (ci - seg0);   // position in the K-row-padded channel space
         float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(((int64_t)k * co_tot + co) * taps + t) * cin_tot + kc];
+        if (live)
+            for (int k = p; k < splits; k += P) s += slab[(((int64_t)k * co_tot + co) * taps + t) * cin_tot + kc];
+#pragma unroll
+        for (int o = OPW; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
+        if (!live || p != 0) continue;
         // ordinary convolution: OIHW [co][ci][tap].  Transposed convolution (ct_cout > 0): the weight is
         // [ci][co][4][4] and tap t of this phase is kernel element ct_k{t}.
         float* d = ct_cout > 0 ? dw + ((int64_t)ci * ct_cout + co) * 16 + (t == 0 ? ct_k0 : t == 1 ? ct_k1 : t == 2 ? ct_k2 : ct_k3)
                                : dw + ((int64_t)co * cin_real + ci) * taps + t;
         *d = accumulate ? *d + s : s;
+    }
+}
+
+static void launch_wgrad_reduce(hipStream_t st, const float* slab, int splits, int64_t co_tot, int taps, int cin_tot, int cout_real,
+                                int cin_real, int seg0, int k0_pad, float* dw, int accumulate, int ct_cout = 0, int k0 = 0, int k1 = 0,
+                                int k2 = 0, int k3 = 0) {
+    const int64_t total = (int64_t)cout_real * cin_real * taps;
+    if (splits >= 32) {
+        int64_t grid = (total * 8 + kConvThreads - 1) / kConvThreads;
+        if (grid > 16384) grid = 16384;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<8>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
+                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3);
+    } else {
+        int64_t grid = (total + kConvThreads - 1) / kConvThreads;
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel<1>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
+                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3);
     }
 }
 
@@ -1172,13 +1202,9 @@ extern "C" int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0,
     const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
     launch_wgrad_any(dtype, taps, a, grid, st, Cout, C0);
     SEGK_LAUNCH_CHECK();
-    const int64_t total = Cout * cin_real * taps;
-    int64_t rgrid = (total + kConvThreads - 1) / kConvThreads;
-    if (rgrid > 8192) rgrid = 8192;
     const int seg0 = C1 ? (int)C0 : (int)cin_real;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(kConvThreads), 0, st, (const float*)workspace, a.splits,
-                       (int64_t)a.ncb * kr, taps, a.nch * kr, (int)Cout, (int)cin_real, seg0, a.nch0 * kr, dw, (flags >> 1) & 1, 0, 0, 0,
-                       0, 0);
+    launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, taps, a.nch * kr, (int)Cout, (int)cin_real, seg0,
+                        a.nch0 * kr, dw, (flags >> 1) & 1);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1302,9 +1328,6 @@ extern "C" int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t C
     a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
     a.slab = (float*)workspace;
     const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
-    const int64_t total = Cout * Cin * 4;
-    int64_t rgrid = (total + kConvThreads - 1) / kConvThreads;
-    if (rgrid > 8192) rgrid = 8192;
     for (int ph = 0; ph < 4; ++ph) {
         const int pa = ph >> 1, pb = ph & 1;
         a.vdy = View{(int)(2 * H), (int)(2 * W), 2, 2, pa, pb};
@@ -1315,9 +1338,8 @@ extern "C" int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t C
         }
         launch_wgrad_any(dtype, 4, a, grid, st, Cout, Cin);
         SEGK_LAUNCH_CHECK();
-        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(kConvThreads), 0, st, (const float*)workspace, a.splits,
-                           (int64_t)a.ncb * kr, 4, a.nch * kr, (int)Cout, (int)Cin, (int)Cin, a.nch0 * kr, dw, (flags >> 1) & 1, (int)Cout,
-                           kidx[0], kidx[1], kidx[2], kidx[3]);
+        launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, 4, a.nch * kr, (int)Cout, (int)Cin, (int)Cin,
+                            a.nch0 * kr, dw, (flags >> 1) & 1, (int)Cout, kidx[0], kidx[1], kidx[2], kidx[3]);
         SEGK_LAUNCH_CHECK();
     }
     return SEGK_OK;
