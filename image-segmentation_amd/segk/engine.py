@@ -26,7 +26,7 @@ class Var:
 
 
 class Runtime:
-    def __init__(self, params, buffers, dtype, device, training, need_grad, grad_sink=None, grad_alloc=None):
+    def __init__(self, params, buffers, dtype, device, training, need_grad, grad_sink=None, grad_alloc=None, zero_state=None):
         self.p, self.b = params, buffers        # name -> tensor
         self.dtype, self.device = dtype, device
         self.training, self.need_grad = training, need_grad
@@ -36,6 +36,10 @@ class Runtime:
         self._keep = []                         # keeps activation buffers alive until backward
         self.grad_sink = grad_sink              # optional callback(name, tensor) fired as soon as a gradient is final
         self.grad_alloc = grad_alloc            # optional callback(name, like) -> tensor to write the gradient into
+        # names whose persistent gradient tensor is known to hold zeros already (only meaningful with grad_alloc, whose
+        # tensors outlive the step): an analytically-zero gradient is then not rewritten every step
+        self.zero_state = zero_state if grad_alloc is not None else None
+        self.counters = []                      # BatchNorm num_batches_tracked buffers to bump once, together
 
     # ---------------------------------------------------------------- buffers
     def new(self, N, H, W, C, zero=False):
@@ -57,6 +61,19 @@ class Runtime:
         if self.grad_alloc is not None:
             return self.grad_alloc(name, like)
         return torch.empty_like(like, dtype=torch.float32)
+
+    def _zero_grad(self, name, tensor):
+        """Write an analytically zero gradient (skipped when the persistent tensor already holds zeros)."""
+        if self.zero_state is not None:
+            if name in self.zero_state:
+                return
+            self.zero_state.add(name)
+        tensor.zero_()
+
+    def finish_forward(self):
+        if self.counters:
+            torch._foreach_add_(self.counters, 1)
+            self.counters = []
 
     def _emit(self, name, tensor):
         self.grads[name] = tensor
@@ -114,8 +131,10 @@ class Runtime:
             if bname is not None:
                 gb = self.alloc_grad(bname, self.p[bname])
                 if bias_grad_zero:
-                    gb.zero_()
+                    self._zero_grad(bname, gb)
                 else:
+                    if self.zero_state is not None:
+                        self.zero_state.discard(bname)
                     gb.copy_(ops.colsum(dy, torch.empty(cs, dtype=torch.float32, device=self.device))[:Cout])
                 self._emit(bname, gb)
         self.record(bwd)
@@ -153,8 +172,10 @@ class Runtime:
             if bname is not None:
                 db = self.alloc_grad(bname, self.p[bname])
                 if bias_grad_zero:
-                    db.zero_()
+                    self._zero_grad(bname, db)
                 else:
+                    if self.zero_state is not None:
+                        self.zero_state.discard(bname)
                     ops.colsum(dy, db)
                 self._emit(bname, db)
             self._dgrad(segs, dy, wb, Cin)
@@ -242,7 +263,7 @@ class Runtime:
         stats = torch.empty(2 * C, dtype=torch.float32, device=self.device)
         if self.training:
             ops.norm_stats(y.act, 1, eps, stats, self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], momentum)
-            self.b[prefix + ".num_batches_tracked"].add_(1)
+            self.counters.append(self.b[prefix + ".num_batches_tracked"])
         else:
             ops.norm_eval_stats(self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], eps, stats)
         a = Var(out or self.new(y.act.N, y.act.H, y.act.W, C))

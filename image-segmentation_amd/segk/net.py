@@ -31,9 +31,12 @@ class _TapeFn(torch.autograd.Function):
         names = net._segk_param_names
         dtype = net.compute_dtype()
         hooks = getattr(net, "_segk_grad_hooks", None) or (None, None, None, None)
+        if not hasattr(net, "_segk_zero_grads"):
+            net._segk_zero_grads = set()
         rt = Runtime(dict(zip(names, params)), dict(net.named_buffers()), dtype, x.device, net.training, need_grad,
-                     grad_sink=hooks[0], grad_alloc=hooks[1])
+                     grad_sink=hooks[0], grad_alloc=hooks[1], zero_state=net._segk_zero_grads)
         logits = net._emit(rt, x)
+        rt.finish_forward()
         ctx.rt, ctx.names, ctx.hooks = rt, names, hooks
         ctx.set_materialize_grads(False)
         return logits
@@ -94,6 +97,7 @@ class _BlockFn(torch.autograd.Function):
                      need_grad)
         v = rt.input(x)
         out = block._emit_block(rt, v)
+        rt.finish_forward()
         ctx.rt, ctx.names, ctx.v, ctx.out = rt, names, v, out
         return out.act.nchw().float().contiguous()
 
