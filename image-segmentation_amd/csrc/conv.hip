@@ -54,6 +54,8 @@ struct ConvArgs {
     int Cout, cout_pad;
     const float* bias;
     char* y; int64_t ldy;
+    char* y1 = nullptr; int64_t ldy1 = 0;   // second destination: output channels >= split go to y1 (channel - split)
+    int split = 1 << 30, accumulate1 = 0;
     const char* mask; int64_t ld_mask; int mask_c;   // output channels below mask_c are zeroed where mask <= 0
     int relu, accumulate;
 };
@@ -305,8 +307,9 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES *
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
             }
-            T* dst = reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
-            if (a.accumulate) {
+            const bool second = co >= a.split;
+            T* dst = second ? reinterpret_cast<T*>(a.y1) + pix * a.ldy1 + (co - a.split) : reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
+            if (second ? a.accumulate1 : a.accumulate) {
                 float o[8];
                 Elem<T>::load8(dst, o);
 #pragma unroll
@@ -511,8 +514,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_res_kernel(const ConvArgs a
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
                     }
-                    T* dst = reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
-                    if (a.accumulate) {
+                    const bool second = co >= a.split;
+                    T* dst = second ? reinterpret_cast<T*>(a.y1) + pix * a.ldy1 + (co - a.split) : reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
+                    if (second ? a.accumulate1 : a.accumulate) {
                         float o[8];
                         Elem<T>::load8(dst, o);
 #pragma unroll
@@ -1131,12 +1135,16 @@ extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, in
 
 extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1, int64_t C1,
                              int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout, const float* bias, void* y,
-                             int64_t ldy, const void* mask, int64_t ld_mask, int64_t mask_channels, int flags, int dev, void* stream) {
+                             int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask, int64_t ld_mask, int64_t mask_channels,
+                             int flags, int dev, void* stream) {
     if (int rc = check_segments("conv_fwd", dtype, x0, ld0, C0, x1, ld1, C1)) return rc;
+    SEGK_REQUIRE(!y1 || (split > 0 && split < Cout && split % 8 == 0 && ldy >= split && ldy1 >= Cout - split && aligned16(y1) &&
+                         (ldy1 * esize(dtype)) % 16 == 0 && !mask),
+                 SEGK_ESHAPE, "conv_fwd: second output needs 0 < split < Cout, split a multiple of 8, aligned y1, and no mask");
     SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_fwd: taps must be 1 or 9");
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_fwd: bad N/H/W");
     SEGK_REQUIRE(w_packed && y && aligned16(w_packed), SEGK_EINVAL, "conv_fwd: null or misaligned weights/output");
-    SEGK_REQUIRE(Cout > 0 && Cout % 8 == 0 && ldy >= Cout, SEGK_ESHAPE, "conv_fwd: Cout %lld must be a multiple of 8 and <= ldy", (long long)Cout);
+    SEGK_REQUIRE(Cout > 0 && Cout % 8 == 0 && (y1 || ldy >= Cout), SEGK_ESHAPE, "conv_fwd: Cout %lld must be a multiple of 8 and <= ldy", (long long)Cout);
     SEGK_REQUIRE(aligned16(y) && (ldy * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_fwd: output pointer/ld misaligned");
     SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "conv_fwd: bias must be 16-byte aligned");
     SEGK_REQUIRE(!mask || (aligned16(mask) && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "conv_fwd: mask misaligned");
@@ -1154,6 +1162,7 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     a.w = (const char*)w_packed; a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
     a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = (const char*)mask; a.ld_mask = ld_mask; a.mask_c = (int)mask_channels;
     a.relu = flags & 1; a.accumulate = (flags >> 1) & 1;
+    if (y1) { a.y1 = (char*)y1; a.ldy1 = ldy1; a.split = (int)split; a.accumulate1 = (flags >> 2) & 1; }
     const int bn = pick_bn(a.cout_pad);
     SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;

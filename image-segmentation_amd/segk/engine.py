@@ -222,15 +222,12 @@ class Runtime:
             for m in members:
                 m.ready = True
             return
-        tmp = self.new(dy.N, dy.H, dy.W, Cin)
-        ops.conv_fwd(dy, wb, Cin, tmp, taps=9)
-        c = 0
-        for act, members in segs:
-            assert mask_of(members) is None
-            ops.copy_slice(tmp.slice(c, act.C), self.grad_of(act), accumulate=state(members))
-            for m in members:
-                m.ready = True
-            c += act.C
+        # two segments: the kernel writes each segment's gradient straight into its own buffer
+        (act0, mem0), (act1, mem1) = segs
+        assert mask_of(mem0) is None and mask_of(mem1) is None
+        ops.conv_fwd(dy, wb, Cin, (self.grad_of(act0), self.grad_of(act1)), taps=9, accumulate=state(mem0), accumulate1=state(mem1))
+        for m in mem0 + mem1:
+            m.ready = True
 
     def conv_transpose_relu(self, h, wname, bname, out=None):
         """ConvTranspose2d(4, stride 2, padding 1) + ReLU (models/unetvgg.py:31-32,41)."""

@@ -152,17 +152,19 @@ def _segs(x):
     return a, b
 
 
-def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, accumulate=False):
+def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, accumulate=False, accumulate1=False):
     """out = conv(x) with the packed image `w_packed`; x is an Act or a pair of Acts (channel concat).
-    mask: Act over the first mask.C output channels; those are zeroed where mask <= 0."""
+    mask: Act over the first mask.C output channels; those are zeroed where mask <= 0.
+    out may be a pair of Acts: channels [0, out[0].C) go to the first, the rest to the second (accumulate1)."""
     a, b = _segs(x)
-    assert out.C == Cout and (out.N, out.H, out.W) == (a.N, a.H, a.W) and out.dtype == a.dtype
+    o0, o1 = (out, None) if isinstance(out, Act) else out
+    assert o0.C + (o1.C if o1 else 0) == Cout and (o0.N, o0.H, o0.W) == (a.N, a.H, a.W) and o0.dtype == a.dtype
     dev, st = _env(a.buf)
-    flags = (RELU if relu else 0) | (ACCUM if accumulate else 0)
+    flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (4 if accumulate1 else 0)
     with _Timed("conv_fwd"):
         call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
-             a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), out.ptr, out.ld, mask.ptr if mask else None,
-             mask.ld if mask else 0, mask.C if mask else 0, flags, dev, st)
+             a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), o0.ptr, o0.ld, o1.ptr if o1 else None, o1.ld if o1 else 0,
+             o0.C if o1 else 0, mask.ptr if mask else None, mask.ld if mask else 0, mask.C if mask else 0, flags, dev, st)
     return out
 
 

@@ -128,11 +128,13 @@ int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, int taps, int
  * models/unetvgg.py:99-103, models/unetplusplus.py:64-79); C0, C1, Cout and mask_channels multiples of 8.
  * flags bit0: ReLU epilogue; mask (optional, same dtype, ld_mask): output channels [0, mask_channels) are zeroed
  * where mask<=0: the ReLU backward of the producer(s) of those channels, fused into the data gradient.
- * flags bit1: accumulate into y (y += result) instead of overwriting.                             */
+ * flags bit1: accumulate into y (y += result) instead of overwriting.
+ * y1 (optional): second destination -- output channels [split, Cout) are written to y1[..., c - split] (flags
+ * bit2: accumulated there); the data gradient of a two-segment input lands directly in both segments' buffers.  */
 int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
                   int64_t C1, int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout,
-                  const float* bias, void* y, int64_t ldy, const void* mask, int64_t ld_mask, int64_t mask_channels,
-                  int flags, int dev, void* stream);
+                  const float* bias, void* y, int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask,
+                  int64_t ld_mask, int64_t mask_channels, int flags, int dev, void* stream);
 
 /* dw[co,ci,ky,kx] (fp32 OIHW, [Cout, cin_real, taps]) = sum_{n,y,x} dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]
  * replaces: the weight-gradient half of Conv2d's backward.  The pixels are split over workgroups

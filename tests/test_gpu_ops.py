@@ -150,7 +150,15 @@ def test_conv_two_segments(dtype):
     dya = to_act(dy, dtype)
     dx = ops.Act.empty(N, H, W, C0 + C1, dtype, "cuda")
     ops.conv_fwd(dya, wb, C0 + C1, dx)
-    report("conv_dgrad_2seg", from_act(dx), F.conv_transpose2d(dy.double(), w.double(), padding=1).float(), **TOL[dtype])
+    ref_dx = F.conv_transpose2d(dy.double(), w.double(), padding=1).float()
+    report("conv_dgrad_2seg", from_act(dx), ref_dx, **TOL[dtype])
+    # the same gradient written straight into the two segments' own buffers (second one accumulated)
+    d0 = ops.Act(torch.zeros(N, H, W, C0 + 8, dtype=dtype, device="cuda"), 8, C0)
+    d1 = ops.Act(torch.ones(N, H, W, C1, dtype=dtype, device="cuda"))
+    ops.conv_fwd(dya, wb, C0 + C1, (d0, d1), accumulate1=True)
+    report("conv_dgrad_2dst_a", from_act(d0), ref_dx[:, :C0], **TOL[dtype])
+    report("conv_dgrad_2dst_b", from_act(d1), ref_dx[:, C0:] + 1.0, **TOL[dtype])
+    assert float(d0.buf[..., :8].float().abs().max()) == 0.0
     dw = torch.empty_like(w, device="cuda")
     ops.conv_wgrad((a0, a1), dya, dw)
     ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1).float()
