@@ -542,116 +542,7 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
 }
 
 // ------------------------------------------------------------------------------ bilinear x2
-struct Lerp { int i0, i1; float w0, w1; };
-
-// source taps of output index `o` (size 2*in) exactly as ATen's upsample_bilinear2d forms them
-__device__ __forceinline__ Lerp lerp_taps(int o, int in, bool align) {
-    float src;
-    if (align) {
-        const float scale = in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f;
-        src = scale * (float)o;
-    } else {
-        src = 0.5f * ((float)o + 0.5f) - 0.5f;
-        if (src < 0.f) src = 0.f;
-    }
-    Lerp l;
-    l.i0 = (int)src;
-    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
-    l.w1 = src - (float)l.i0;
-    l.w0 = 1.f - l.w1;
-    return l;
-}
-
-template <typename T>
-__global__ __launch_bounds__(kThreads) void upsample_fwd_kernel(const T* __restrict__ x, int64_t ldx, int64_t N, int H, int W,
-                                                                int C, const float* __restrict__ stats, int relu, int align,
-                                                                T* __restrict__ y, int64_t ldy) {
-    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
-    const int64_t items = N * Ho * Wo * cv;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
-        const int v = (int)(i % cv);
-        int64_t p = i / cv;
-        const int ox = (int)(p % Wo); p /= Wo;
-        const int oy = (int)(p % Ho);
-        const int64_t n = p / Ho;
-        const Lerp ly = lerp_taps(oy, H, align != 0), lx = lerp_taps(ox, W, align != 0);
-        const T* b = x + n * H * W * ldx + v * 8;
-        float a00[8], a01[8], a10[8], a11[8], o[8];
-        Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i0) * ldx, a00);
-        Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i1) * ldx, a01);
-        Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i0) * ldx, a10);
-        Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i1) * ldx, a11);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float val = ly.w0 * (lx.w0 * a00[j] + lx.w1 * a01[j]) + ly.w1 * (lx.w0 * a10[j] + lx.w1 * a11[j]);
-            if (stats) {
-                const int c = v * 8 + j;
-                val = (val - stats[(n * C + c) * 2]) * stats[(n * C + c) * 2 + 1];
-            }
-            o[j] = relu ? fmaxf(val, 0.f) : val;
-        }
-        Elem<T>::store8(y + ((n * Ho + oy) * Wo + ox) * ldy + v * 8, o);
-    }
-}
-
-// adjoint of the interpolation (gather form): every input pixel collects from the output pixels whose
-// taps include it.  For x2 up-sampling those lie in [2h-3, 2h+3] for either corner convention.
-template <typename T>
-__global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy,
-                                                                const T* __restrict__ y, int64_t ldy, int64_t N, int H, int W,
-                                                                int C, int relu, int align, T* __restrict__ dx,
-                                                                int64_t ld_dx) {
-    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
-    const int64_t items = N * H * W * cv;
-    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
-        const int v = (int)(i % cv);
-        int64_t p = i / cv;
-        const int w = (int)(p % W); p /= W;
-        const int h = (int)(p % H);
-        const int64_t n = p / H;
-        float wy[7], wx[7];
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const int oy = 2 * h - 3 + k, ox = 2 * w - 3 + k;
-            wy[k] = 0.f; wx[k] = 0.f;
-            if (oy >= 0 && oy < Ho) {
-                const Lerp l = lerp_taps(oy, H, align != 0);
-                wy[k] = (l.i0 == h ? l.w0 : 0.f) + (l.i1 == h ? l.w1 : 0.f);
-            }
-            if (ox >= 0 && ox < Wo) {
-                const Lerp l = lerp_taps(ox, W, align != 0);
-                wx[k] = (l.i0 == w ? l.w0 : 0.f) + (l.i1 == w ? l.w1 : 0.f);
-            }
-        }
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-        for (int ky = 0; ky < 7; ++ky) {
-            if (wy[ky] == 0.f) continue;
-            const int oy = 2 * h - 3 + ky;
-            for (int kx = 0; kx < 7; ++kx) {
-                if (wx[kx] == 0.f) continue;
-                const int ox = 2 * w - 3 + kx;
-                const int64_t op = (n * Ho + oy) * Wo + ox;
-                float d[8];
-                Elem<T>::load8(dy + op * ld_dy + v * 8, d);
-                const float wgt = wy[ky] * wx[kx];
-                if (relu) {
-                    float f[8];
-                    Elem<T>::load8(y + op * ldy + v * 8, f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += (f[j] > 0.f) ? wgt * d[j] : 0.f;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] += wgt * d[j];
-                }
-            }
-        }
-        Elem<T>::store8(dx + ((n * H + h) * W + w) * ld_dx + v * 8, acc);
-    }
-}
-
-// Work decomposition of the resampling kernels: a block owns a TY x 8 patch of LOW-resolution pixels times a group of
+// Work decomposition of the resampling kernels: a block owns a TY x 8 patch of pixels times a group of
 // CG channel vectors (TY*8*CG = 256 threads), so that the overlapping neighbourhoods of adjacent pixels are served
 // by the block's own L1 instead of being fetched once per XCD (consecutive blocks run on different XCDs, whose L2s
 // do not share lines).
@@ -674,6 +565,110 @@ __device__ __forceinline__ PatchItem patch_item(int64_t block, int tid, int H, i
     it.h = tyi * ty + tid / (cg * 8);
     it.ok = it.h < H && it.w < W;
     return it;
+}
+
+
+struct Lerp { int i0, i1; float w0, w1; };
+
+// source taps of output index `o` (size 2*in) exactly as ATen's upsample_bilinear2d forms them
+__device__ __forceinline__ Lerp lerp_taps(int o, int in, bool align) {
+    float src;
+    if (align) {
+        const float scale = in > 1 ? (float)(in - 1) / (float)(2 * in - 1) : 0.f;
+        src = scale * (float)o;
+    } else {
+        src = 0.5f * ((float)o + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    Lerp l;
+    l.i0 = (int)src;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_fwd_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
+                                                                const float* __restrict__ stats, int relu, int align,
+                                                                T* __restrict__ y, int64_t ldy) {
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, Ho, Wo, cv);   // one OUTPUT pixel (8 channels) per thread
+    if (!it.ok) return;
+    const int oy = it.h, ox = it.w, v = it.v;
+    const int64_t n = it.n;
+    const Lerp ly = lerp_taps(oy, H, align != 0), lx = lerp_taps(ox, W, align != 0);
+    const T* b = x + n * H * W * ldx + v * 8;
+    float a00[8], a01[8], a10[8], a11[8], o[8];
+    Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i0) * ldx, a00);
+    Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i1) * ldx, a01);
+    Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i0) * ldx, a10);
+    Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i1) * ldx, a11);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float val = ly.w0 * (lx.w0 * a00[j] + lx.w1 * a01[j]) + ly.w1 * (lx.w0 * a10[j] + lx.w1 * a11[j]);
+        if (stats) {
+            const int c = v * 8 + j;
+            val = (val - stats[(n * C + c) * 2]) * stats[(n * C + c) * 2 + 1];
+        }
+        o[j] = relu ? fmaxf(val, 0.f) : val;
+    }
+    Elem<T>::store8(y + ((n * Ho + oy) * Wo + ox) * ldy + v * 8, o);
+}
+
+// adjoint of the interpolation (gather form): every input pixel collects from the output pixels whose
+// taps include it.  For x2 up-sampling those lie in [2h-3, 2h+3] for either corner convention.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy,
+                                                                const T* __restrict__ y, int64_t ldy, int H, int W, int C,
+                                                                int relu, int align, T* __restrict__ dx, int64_t ld_dx) {
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, H, W, cv);     // one INPUT pixel (8 channels) per thread
+    if (!it.ok) return;
+    const int h = it.h, w = it.w, v = it.v;
+    const int64_t n = it.n;
+    float wy[7], wx[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const int oy = 2 * h - 3 + k, ox = 2 * w - 3 + k;
+        wy[k] = 0.f; wx[k] = 0.f;
+        if (oy >= 0 && oy < Ho) {
+            const Lerp l = lerp_taps(oy, H, align != 0);
+            wy[k] = (l.i0 == h ? l.w0 : 0.f) + (l.i1 == h ? l.w1 : 0.f);
+        }
+        if (ox >= 0 && ox < Wo) {
+            const Lerp l = lerp_taps(ox, W, align != 0);
+            wx[k] = (l.i0 == w ? l.w0 : 0.f) + (l.i1 == w ? l.w1 : 0.f);
+        }
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+        if (wy[ky] == 0.f) continue;
+        const int oy = 2 * h - 3 + ky;
+        float row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = 0.f;
+        for (int kx = 0; kx < 7; ++kx) {
+            if (wx[kx] == 0.f) continue;
+            const int ox = 2 * w - 3 + kx;
+            const int64_t op = (n * Ho + oy) * Wo + ox;
+            float d[8];
+            Elem<T>::load8(dy + op * ld_dy + v * 8, d);
+            if (relu) {
+                float f[8];
+                Elem<T>::load8(y + op * ldy + v * 8, f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) d[j] = f[j] > 0.f ? d[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) row[j] += wx[kx] * d[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy[ky] * row[j];
+    }
+    Elem<T>::store8(dx + ((n * H + h) * W + w) * ld_dx + v * 8, acc);
 }
 
 // Fast paths for align_corners=False (the decoder blocks): with scale 2 the taps are fixed.  Output rows 2h and
@@ -1208,10 +1203,9 @@ extern "C" int segk_upsample2x_fwd(int dtype, const void* x, int64_t ldx, int64_
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
-    const int64_t items = N * 4 * H * W * (C / 8);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
-                                                     (const T*)x, ldx, N, (int)H, (int)W, (int)C, stats, flags & 1, (flags >> 2) & 1,
-                                                     (T*)y, ldy));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3((unsigned)patch_blocks(N, 2 * H, 2 * W, C)), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)x, ldx, (int)H, (int)W, (int)C, stats, flags & 1,
+                                                     (flags >> 2) & 1, (T*)y, ldy));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1223,7 +1217,6 @@ extern "C" int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, con
     if (flags & 1) SEGK_CHECK_ACT("upsample_bwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0, SEGK_ESHAPE, "upsample_bwd: bad shape");
     SEGK_HIP(use_device(dev));
-    const int64_t items = N * H * W * (C / 8);
     if (!((flags >> 2) & 1)) {
         SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_half_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
                                                          (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, (int)H, (int)W,
@@ -1231,9 +1224,9 @@ extern "C" int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, con
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
-                                                     (const T*)dy, ld_dy, (const T*)y, ldy, N, (int)H, (int)W, (int)C, flags & 1,
-                                                     (flags >> 2) & 1, (T*)dx, ld_dx));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, (int)H, (int)W, (int)C,
+                                                     flags & 1, (flags >> 2) & 1, (T*)dx, ld_dx));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
