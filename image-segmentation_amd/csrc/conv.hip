@@ -56,6 +56,7 @@ struct ConvArgs {
     char* y; int64_t ldy;
     char* y1 = nullptr; int64_t ldy1 = 0;   // second destination: output channels >= split go to y1 (channel - split)
     int split = 1 << 30, accumulate1 = 0;
+    int xcd_remap = 1;
     const char* mask; int64_t ld_mask; int mask_c;   // output channels below mask_c are zeroed where mask <= 0
     int relu, accumulate;
 };
@@ -144,8 +145,16 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES *
     // block -> (output-channel block, image, tile): channel block slowest so that concurrently
     // resident workgroups stream the same weight slab through L2.
     const int nsp = a.N * a.tiles_y * a.tiles_x;
-    const int cb = blockIdx.x / nsp;
-    int sp = blockIdx.x % nsp;
+    // Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.
+    // Renumber so that each XCD works through ONE contiguous eighth of the (channel block, tile) list: neighbouring
+    // tiles, whose halos overlap, then share an L2 instead of each fetching the overlap from beyond it.
+    int vb = blockIdx.x;
+    if (a.xcd_remap) {
+        const int G = gridDim.x, base = G >> 3, rem = G & 7, x = vb & 7;
+        vb = x * base + (x < rem ? x : rem) + (vb >> 3);
+    }
+    const int cb = vb / nsp;
+    int sp = vb % nsp;
     const int tx = sp % a.tiles_x; sp /= a.tiles_x;
     const int ty = sp % a.tiles_y;
     const int n = sp / a.tiles_y;
@@ -1163,6 +1172,8 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     a.bias = bias; a.y = (char*)y; a.ldy = ldy; a.mask = (const char*)mask; a.ld_mask = ld_mask; a.mask_c = (int)mask_channels;
     a.relu = flags & 1; a.accumulate = (flags >> 1) & 1;
     if (y1) { a.y1 = (char*)y1; a.ldy1 = ldy1; a.split = (int)split; a.accumulate1 = (flags >> 2) & 1; }
+    static const int remap = getenv("SEGK_XCD_REMAP") ? atoi(getenv("SEGK_XCD_REMAP")) : 1;
+    a.xcd_remap = remap;
     const int bn = pick_bn(a.cout_pad);
     SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
