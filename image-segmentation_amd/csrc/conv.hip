@@ -14,7 +14,6 @@
 // MFMA orientation (forward): A = weights (rows = output channels), B = pixels (columns), so a lane's
 // four accumulator registers are four CONSECUTIVE output channels of one pixel -> one 8/16-byte store.
 #include "common.h"
-#include <type_traits>
 #include <stdlib.h>
 
 namespace segk {
@@ -112,8 +111,13 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
     return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
 }
 
-template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES>
-__global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES * WCO_WAVES)) void conv_fwd_kernel(const ConvArgs a) {
+// WGS: workgroups per CU the kernel is built for.  2 (default): two halo buffers, the next K-row's halo streams in behind
+// the MFMAs.  3 or 4 (thin layers, one or two K-rows: memory-latency bound, few steps per tile): ONE halo buffer and no
+// halo prefetch, 33-49 KB of LDS and <= 128/170 registers, so that three or four workgroups share a CU and their
+// load phases overlap each other's MFMAs.
+template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES, int WGS = 2>
+__global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_WAVES * WCO_WAVES)) void conv_fwd_kernel(const ConvArgs a) {
+    constexpr bool ONE_HALO = WGS > 2;
     constexpr int NT = 64 * WPX_WAVES * WCO_WAVES;   // threads: 4 waves (two workgroups per CU) or 8 waves (one)
     constexpr int PAD = TAPS == 1 ? 0 : 1;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_;
@@ -132,9 +136,10 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES *
     constexpr int HBYTES = HPARTS * HL * NT * 16, WBYTES = BN * kRowBytes;
 
     // one LDS object: [halo 0 | halo 1 | weights 0 | weights 1]
-    __shared__ __attribute__((aligned(16))) char smem[2 * HBYTES + 2 * WBYTES];
+    constexpr int NHALO = ONE_HALO ? 1 : 2;
+    __shared__ __attribute__((aligned(16))) char smem[NHALO * HBYTES + 2 * WBYTES];
     char* const s_halo0 = smem;
-    char* const s_w0 = smem + 2 * HBYTES;
+    char* const s_w0 = smem + NHALO * HBYTES;
     const unsigned lds0 = lds_address(smem);
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES *
         const char* src = wsrc0 + (int64_t)step * a.cout_pad * kRowBytes;
 #pragma unroll
         for (int k = 0; k < WL; ++k)
-            glds16_hidden(src + k * NT * 16, lds0 + 2 * HBYTES + buf * WBYTES + (k * NT + wave * 64) * 16);
+            glds16_hidden(src + k * NT * 16, lds0 + NHALO * HBYTES + buf * WBYTES + (k * NT + wave * 64) * 16);
     };
 
     const int nsteps = a.nch * TAPS;
@@ -223,8 +228,16 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES *
         // convolution, the tail of a 96-channel concat) is multiplied with one k-substep instead of two
         const int rc = chunk < a.nch0 ? a.C0 - chunk * KRow<T>::kElems : a.C1 - (chunk - a.nch0) * KRow<T>::kElems;
         const int nks = rc > KRow<T>::kElems / 2 ? 2 : 1;
-        const bool next_chunk = chunk + 1 < a.nch;
-        const char* hb = s_halo0 + (chunk & 1) * HBYTES;
+        const bool next_chunk = !ONE_HALO && chunk + 1 < a.nch;
+        const char* hb = s_halo0 + (ONE_HALO ? 0 : (chunk & 1)) * HBYTES;
+        if (ONE_HALO && chunk > 0) {
+            // single halo buffer: everyone has passed the previous K-row's last barrier, so the buffer is free
+#pragma unroll
+            for (int part = 0; part < HPARTS; ++part) stage_halo_part(chunk, 0, part);
+            dma_wait_all();
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         auto tap_ky = [&](int tap) { return TAPS == 9 ? tap / 3 : (TAPS == 4 ? a.tky[tap] : 0); };
         auto tap_kx = [&](int tap) { return TAPS == 9 ? tap % 3 : (TAPS == 4 ? a.tkx[tap] : 0); };
         auto load_b = [&](int tap, int ks, Slot (&fb)[NJ]) {
@@ -325,215 +338,6 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, 512 / (64 * WPX_WAVES *
                 for (int r = 0; r < 8; ++r) v[r] += o[r];
             }
             Elem<T>::store8(dst, v);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward / data-gradient kernel for THIN layers (one or two K-rows of input channels, 3x3 taps)
-// ------------------------------------------------------------------------------------------------
-// With so few input channels a spatial tile carries only 9 or 18 (K-row, tap) steps, and the general kernel spends
-// its time on per-tile latencies (first halo, epilogue) and on re-staging the same few weights for every tile.
-// Here all weights of the workgroup's output-channel block stay resident in LDS (<= 72 KB), one workgroup per CU
-// walks a strided sequence of 16x16-pixel tiles, the halo of the next (tile, K-row) streams in by DMA behind the
-// MFMAs of the current one, and the only barrier is the one that swaps the two halo buffers.
-// Wave w owns tile rows 4w .. 4w+3 and all BN output channels.  One wave per SIMD means that nothing but the
-// wave's own instruction order hides latency, hence the explicit software pipeline below and the effort to keep
-// the per-tile address arithmetic short.
-template <typename T, int BN>
-__global__ __launch_bounds__(kConvThreads) void conv_res_kernel(const ConvArgs a, const int streams) {
-    constexpr int TAPS = 9, TH = 16, PAD = 1;
-    constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_, HSLOTS = HPIX * 8;
-    constexpr int HL = (HSLOTS + kConvThreads - 1) / kConvThreads;   // halo transfers per thread per K-row (the last one partial)
-    constexpr int HBYTES = HSLOTS * 16;
-    constexpr int NI = BN / 16, NJ = TH / 4;
-    constexpr int EPS = 16 / (int)sizeof(T);
-    constexpr int KR = KRow<T>::kElems;
-    constexpr int kMaxRows = 64 * TAPS;   // nch * BN <= 64 rows per tap
-    static_assert(BN == 32 || BN == 64, "resident-weight kernel: 32 or 64 output channels per workgroup");
-
-    __shared__ __attribute__((aligned(16))) char smem[2 * HBYTES + kMaxRows * kRowBytes];
-    char* const s_w = smem + 2 * HBYTES;
-    const unsigned lds0 = lds_address(smem);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, l15 = lane & 15;
-    const int cb = blockIdx.x / streams, sidx = blockIdx.x % streams;
-    const int ntiles = a.N * a.tiles_y * a.tiles_x;
-
-    auto coords = [&](int tile, int& n, int& y0, int& x0) {
-        const int tx = tile % a.tiles_x; tile /= a.tiles_x;
-        y0 = (tile % a.tiles_y) * TH; x0 = tx * kTW;
-        n = tile / a.tiles_y;
-    };
-    // Halo transfer k of this thread fills LDS slot q = k*256 + tid: halo pixel q>>3 (row hy, column hx), channel slot
-    // (q&7) ^ (pixel&7) (the swizzle is applied on the source side).  Tile-independent, kept in registers:
-    // hy<<8 | hx (or -1 past the halo), the pixel offset from the tile's first pixel, and the channel offset.
-    int hyx[HL], hpo[HL], hch[HL];
-#pragma unroll
-    for (int k = 0; k < HL; ++k) {
-        const int q = k * kConvThreads + tid;
-        const int pix = q >> 3;
-        const int hy = pix / HW_, hx = pix - hy * HW_;
-        hyx[k] = q < HSLOTS ? ((hy << 8) | hx) : -1;
-        hpo[k] = (hy - PAD) * a.W + (hx - PAD);
-        hch[k] = ((q & 7) ^ (pix & 7)) * EPS;
-    }
-    auto stage_halo = [&](int n, int y0, int x0, int chunk, int buf, int k) {
-        const bool s0 = chunk < a.nch0;
-        const char* base = s0 ? a.x0 : a.x1;
-        const int64_t ld = s0 ? a.ld0 : a.ld1;
-        const int ch0 = (s0 ? chunk : chunk - a.nch0) * KR;
-        const int crem = (s0 ? a.C0 : a.C1) - ch0;
-        const int gy = y0 - PAD + (hyx[k] >> 8), gx = x0 - PAD + (hyx[k] & 255);
-        const bool ok = hyx[k] >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && hch[k] < crem;
-        const int64_t pix = (int64_t)((n * a.H + y0) * a.W + x0 + hpo[k]);
-        const char* src = ok ? base + (pix * ld + ch0 + hch[k]) * (int64_t)sizeof(T) : reinterpret_cast<const char*>(&kZeroSlot);
-        if (k < HL - 1 || hyx[k] >= 0) glds16_hidden(src, lds0 + buf * HBYTES + (k * kConvThreads + wave * 64) * 16);
-    };
-
-    // ---- prologue: every weight of this channel block, halo of the first tile ---------------------------------
-    for (int blk = 0; blk < a.nch * TAPS; ++blk) {
-        const char* src = a.w + ((int64_t)blk * a.cout_pad + (int64_t)cb * BN) * kRowBytes + (int64_t)tid * 16;
-#pragma unroll
-        for (int k = 0; k < BN * 8 / kConvThreads; ++k)
-            glds16_hidden(src + k * kConvThreads * 16, lds0 + 2 * HBYTES + (blk * BN * 8 + k * kConvThreads + wave * 64) * 16);
-    }
-    if (sidx < ntiles) {
-        int n, y0, x0;
-        coords(sidx, n, y0, x0);
-#pragma unroll
-        for (int k = 0; k < HL; ++k) stage_halo(n, y0, x0, 0, 0, k);
-    }
-    // bias of the 8 channels this lane stores per tile pair
-    float bias[NI / 2][8];
-#pragma unroll
-    for (int k2 = 0; k2 < NI / 2; ++k2) {
-        const int co = cb * BN + 32 * k2 + 8 * g;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) bias[k2][e] = (a.bias && co + e < a.Cout) ? a.bias[co + e] : 0.f;
-    }
-    dma_wait_all();
-    __syncthreads();
-
-    f32x4 acc[NI][NJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int hp_l = wave * NJ * HW_ + l15;
-
-    int buf = 0;
-    for (int tile = sidx; tile < ntiles; tile += streams) {
-        int n, y0, x0, nn, ny0, nx0;
-        coords(tile, n, y0, x0);
-        coords(tile + streams, nn, ny0, nx0);
-        for (int chunk = 0; chunk < a.nch; ++chunk, buf ^= 1) {
-            const bool last_chunk = chunk == a.nch - 1;
-            const int nchunk = last_chunk ? 0 : chunk + 1;
-            const bool has_next = !last_chunk || tile + streams < ntiles;
-            const int sn = last_chunk ? nn : n, sy0 = last_chunk ? ny0 : y0, sx0 = last_chunk ? nx0 : x0;   // tile being staged
-            const int rc = chunk < a.nch0 ? a.C0 - chunk * KR : a.C1 - (chunk - a.nch0) * KR;
-            const int nks = rc > KR / 2 ? 2 : 1;
-            const char* hb = smem + buf * HBYTES;
-            const char* wb = s_w + chunk * TAPS * BN * kRowBytes;
-            // The fragments of step s+1 are read into a second register set while the MFMAs of step s issue
-            // (steps = taps x k-substeps, fully unrolled).
-            auto load_frags = [&](int tap, int ks, Slot (&fa)[NI], Slot (&fb)[NJ]) {
-                const int ky = tap / 3, kx = tap % 3, slot = ks * 4 + g;
-                // in the order the MFMAs (channel tile outer, pixel row inner) consume them
-                auto rd_a = [&](int i) {
-                    const int co = l15 + i * 16;
-                    fa[i] = *reinterpret_cast<const Slot*>(wb + (tap * BN + co) * kRowBytes + ((slot ^ (co & 7)) << 4));
-                };
-                rd_a(0);
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    const int hp = hp_l + (j + ky) * HW_ + kx;
-                    fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
-                }
-#pragma unroll
-                for (int i = 1; i < NI; ++i) rd_a(i);
-            };
-            auto run_chunk = [&](auto nks_tag) {
-                constexpr int NKS = decltype(nks_tag)::value, STEPS = TAPS * NKS;
-                Slot fa[2][NI], fb[2][NJ];
-                load_frags(0, 0, fa[0], fb[0]);
-#pragma unroll
-                for (int step = 0; step < STEPS; ++step) {
-                    const int tap = step / NKS;
-                    if (step + 1 < STEPS) load_frags((step + 1) / NKS, (step + 1) % NKS, fa[(step + 1) & 1], fb[(step + 1) & 1]);
-                    // the whole next halo goes out during the first taps, so that its HBM latency has the rest of the
-                    // K-row's MFMAs to hide behind
-                    if (step % NKS == 0 && tap < 3 && has_next) {
-#pragma unroll
-                        for (int k = tap; k < HL; k += 3) stage_halo(sn, sy0, sx0, nchunk, buf ^ 1, k);
-                    }
-#pragma unroll
-                    for (int i = 0; i < NI; ++i)
-#pragma unroll
-                        for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[step & 1][i], fb[step & 1][j], acc[i][j]);
-                    // Issue order of this step: one LDS read of the NEXT step's fragments after every two MFMAs.  A burst of
-                    // reads would stall behind the LDS pipe (all four waves burst together after the barrier), and reads
-                    // sunk to just before their use would expose their latency; spread out, each lands >= 10 MFMAs early.
-                    if (step + 1 < STEPS) {
-#pragma unroll
-                        for (int k = 0; k < NI + NJ; ++k) {
-                            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                     // 1 DS read
-                            __builtin_amdgcn_sched_group_barrier(0x008, NI * NJ / (NI + NJ), 0);   // MFMAs
-                        }
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            };
-            if (nks == 2) run_chunk(std::integral_constant<int, 2>{});
-            else run_chunk(std::integral_constant<int, 1>{});
-            // the next halo has landed and everyone is done with this one before the buffers swap
-            __builtin_amdgcn_sched_barrier(0);
-            dma_wait_all();
-            __syncthreads();
-            if (!last_chunk) continue;
-
-            // ---- epilogue of the tile: bias, ReLU, mask, 8 consecutive channels (16 bytes in bf16) per lane ----
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int yy = y0 + wave * NJ + j, xx = x0 + l15;
-                const bool inside = yy < a.H && xx < a.W;
-                const int64_t pix = inside ? (int64_t)(n * a.H + yy) * a.W + xx : 0;
-#pragma unroll
-                for (int k2 = 0; k2 < NI / 2; ++k2) {
-                    const int co = cb * BN + 32 * k2 + 8 * g;
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = acc[2 * k2][j][e] + bias[k2][e];
-                        v[4 + e] = acc[2 * k2 + 1][j][e] + bias[k2][4 + e];
-                    }
-                    acc[2 * k2][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc[2 * k2 + 1][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (!inside || co >= a.Cout) continue;
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
-                    }
-                    if (a.mask && co < a.mask_c) {
-                        float m[8];
-                        Elem<T>::load8(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
-                    }
-                    const bool second = co >= a.split;
-                    T* dst = second ? reinterpret_cast<T*>(a.y1) + pix * a.ldy1 + (co - a.split) : reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
-                    if (second ? a.accumulate1 : a.accumulate) {
-                        float o[8];
-                        Elem<T>::load8(dst, o);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += o[e];
-                    }
-                    Elem<T>::store8(dst, v);
-                }
-            }
         }
     }
 }
@@ -1004,6 +808,15 @@ static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
     const unsigned grid = (unsigned)((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn));
     // (a 16x16-pixel tile on 8 waves, <T, TAPS, 16, 128, 4, 2>, halves the weight traffic into LDS per FLOP but measured
     // 2-5 % slower on the UNet-VGG layers: one 8-wave barrier domain per CU instead of two independent 4-wave ones)
+    if constexpr (TAPS == 9 && sizeof(T) == 2) {
+        // thin layers (one or two K-rows of input channels): the high-occupancy variants
+        if (a.nch <= 2 && bn != 128) {
+            if (bn == 96) hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 96, 4, 1, 3>), dim3(grid), dim3(kConvThreads), 0, st, a);
+            else if (bn == 64) hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 64, 2, 2, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
+            else hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 32, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
+            return;
+        }
+    }
     if (bn == 128)
         hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 128, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else if (bn == 96)
@@ -1012,37 +825,6 @@ static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
         hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 64, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else
         hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 32, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);
-}
-
-// Thin layers (bf16, 3x3): resident-weight kernel.  Returns false when the layer does not qualify.
-static int device_cus(int dev) {
-    static int cus[64] = {0};
-    if (dev < 0 || dev >= 64) return 256;
-    if (cus[dev] == 0) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus[dev] = v;
-    }
-    return cus[dev];
-}
-static bool launch_fwd_resident(int dtype, int taps, ConvArgs a, int dev, hipStream_t st) {
-    static const bool off = getenv("SEGK_NO_RESIDENT") != nullptr;
-    if (off || dtype != SEGK_BF16 || taps != 9 || a.H < 16 || a.W < 16) return false;
-    // one channel block only: with several, every block would re-read the input and the general kernel wins
-    int bn;
-    if (a.nch == 1 && a.cout_pad <= 64) bn = a.cout_pad;
-    else if (a.nch == 2 && a.cout_pad == 32) bn = 32;
-    else return false;
-    a.tiles_y = (a.H + 15) / 16;
-    const int64_t ntiles = (int64_t)a.N * a.tiles_y * a.tiles_x;
-    const int cbs = a.cout_pad / bn, cus = device_cus(dev);
-    if (ntiles < 2 * cus) return false;   // too few tiles to stream: the general kernel spreads them better
-    int streams = cus / cbs;
-    if (streams < 1) streams = 1;
-    const unsigned grid = (unsigned)(streams * cbs);
-    if (bn == 64) hipLaunchKernelGGL((conv_res_kernel<bf16, 64>), dim3(grid), dim3(kConvThreads), 0, st, a, streams);
-    else hipLaunchKernelGGL((conv_res_kernel<bf16, 32>), dim3(grid), dim3(kConvThreads), 0, st, a, streams);
-    return true;
 }
 
 static void launch_fwd_any(int dtype, int taps, const ConvArgs& a, int bn, hipStream_t st) {
@@ -1177,7 +959,7 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     const int bn = pick_bn(a.cout_pad);
     SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    if (!launch_fwd_resident(dtype, taps, a, dev, st)) launch_fwd_any(dtype, taps, a, bn, st);
+    launch_fwd_any(dtype, taps, a, bn, st);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

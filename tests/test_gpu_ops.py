@@ -89,8 +89,8 @@ def test_conv_fwd_dgrad_wgrad(dtype, case):
 
 
 THIN_CASES = [
-    # N, H, W, C0, C1, Cout: enough 16x16 tiles (>= 2 per CU) for the resident-weight kernel of thin bf16 layers
-    (2, 256, 256, 64, 0, 64),     # one K-row, 64-channel block; its data gradient takes the same kernel
+    # N, H, W, C0, C1, Cout: thin bf16 layers (one or two K-rows in) at sizes that fill the device several times over
+    (2, 256, 256, 64, 0, 64),     # one K-row, 64-channel block (four workgroups per CU); same for its data gradient
     (2, 200, 328, 64, 0, 128),    # ragged borders, two channel blocks
     (2, 208, 320, 32, 64, 32),    # two segments (half K-row + K-row), 32-channel block; data gradient: 3 blocks of 32
     (2, 256, 272, 128, 0, 32),    # two K-rows
@@ -100,7 +100,7 @@ THIN_CASES = [
 
 @pytest.mark.parametrize("case", THIN_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_thin_layers_bf16(case):
-    """Thin layers at sizes where the resident-weight kernel is selected: forward (+bias, ReLU), data gradient
+    """Thin layers (high-occupancy kernel variants with a single halo buffer): forward (+bias, ReLU), data gradient
     (+leading-channel mask, accumulate) against ATen in fp64."""
     from segk import ops
     dtype = torch.bfloat16
