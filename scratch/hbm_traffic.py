@@ -1,0 +1,32 @@
+"""HBM bytes per kernel launch from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, one program run each):
+    python scratch/hbm_traffic.py fetch_counter_collection.csv write_counter_collection.csv STEPS > profiles/...json
+Both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes, so reads are doubled."""
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        acc[r["Kernel_Name"]].append(float(r["Counter_Value"]) * 1024)
+    return acc
+
+
+fetch, write, steps = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), float(sys.argv[3])
+kernels, conv, total = {}, 0.0, 0.0
+for name in sorted(fetch, key=lambda k: -sum(fetch[k]) * 2 - sum(write.get(k, []))):
+    rd, wr = 2 * sum(fetch[name]), sum(write.get(name, []))
+    n = len(fetch[name])
+    total += rd + wr
+    if ("conv_fwd_kernel" in name or "conv_wgrad_kernel" in name):
+        conv += rd + wr
+    kernels[name] = {"launches_per_step": round(n / steps, 2), "hbm_read_bytes_per_launch": int(rd / n),
+                     "hbm_write_bytes_per_launch": int(wr / n)}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1`; "
+                     "KiB counters; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)",
+           "steps_profiled": steps,
+           "conv_mfma_kernels_hbm_bytes_per_step": int(conv / steps),
+           "all_kernels_hbm_bytes_per_step": int(total / steps),
+           "kernels": kernels}, sys.stdout, indent=1)
