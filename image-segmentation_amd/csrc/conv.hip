@@ -58,6 +58,7 @@ struct ConvArgs {
     int xcd_remap = 1;
     const char* mask; int64_t ld_mask; int mask_c;   // output channels below mask_c are zeroed where mask <= 0
     int relu, accumulate;
+    int depth = 0, kd = 0;            // volumes: image n is slice n % depth; the input is read from slice n + kd (zero outside the volume)
 };
 
 __device__ __forceinline__ Slot zero_slot() { return make_uint4(0u, 0u, 0u, 0u); }
@@ -164,6 +165,9 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
     const int ty = sp % a.tiles_y;
     const int n = sp / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * kTW;
+    // depth tap of a volume convolution: the neighbouring slice n + kd, or nothing at the volume's faces
+    const bool slice_ok = a.depth == 0 || (unsigned)(n % a.depth + a.kd) < (unsigned)a.depth;
+    if (!slice_ok && a.accumulate) return;   // block-uniform: y += 0
 
     // ---- staging: global -> LDS by DMA (no registers, stays in flight behind the MFMAs) -------------
     // LDS slot q of the halo image holds pixel q>>3, and -- because the DMA destination is linear in the
@@ -178,8 +182,8 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
         const int pix = q >> 3, sl = (q & 7) ^ (pix & 7);
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
-        const bool in = q < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-        hinfo[p] = in ? ((a.vin.pixel(n, gy, gx) << 3) | sl) : -1;
+        const bool in = q < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && slice_ok;
+        hinfo[p] = in ? ((a.vin.pixel(n + a.kd, gy, gx) << 3) | sl) : -1;
     }
     // transfers of halo part `part` (HL per thread) of K-row `chunk` into halo buffer `buf`
     auto stage_halo_part = [&](int chunk, int buf, int part) {
@@ -347,7 +351,8 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
-                                                                 int seg0, char* __restrict__ wf, char* __restrict__ wb) {
+                                                                 int seg0, char* __restrict__ wf, char* __restrict__ wb,
+                                                                 int64_t w_so, int64_t w_si) {
     constexpr int EPS = 16 / (int)sizeof(T);
     constexpr int KR = KRow<T>::kElems;
     // forward image: rows = Cout rounded up to 32 per (chunk,tap); K = input channels, each input
@@ -379,7 +384,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __
                 if (k < k0_pad) ci = k < seg0 ? k : -1;
                 else ci = seg0 + (k - k0_pad);
             } else { co = k; ci = row_channel(row); t = taps - 1 - tap; }
-            v[j] = (co < Cout && ci >= 0 && ci < Cin) ? w[((int64_t)co * Cin + ci) * taps + t] : 0.f;
+            v[j] = (co < Cout && ci >= 0 && ci < Cin) ? w[co * w_so + ci * w_si + t] : 0.f;
         }
         char* dst = (fwd ? wf : wb) + (((int64_t)chunk * taps + tap) * rows + row) * kRowBytes + ((sl ^ (row & 7)) << 4);
         if constexpr (sizeof(T) == 2) {
@@ -461,6 +466,7 @@ struct WgradArgs {
     int Cout, ncb;            // dy channels, output-channel blocks (of KRow elems)
     int splits, tiles_per_split;
     float* slab;              // [splits][ncb*KR][TAPS][nch*KR]
+    int depth = 0, kd = 0;    // volumes: x is read from slice n + kd of the volume that holds slice n (zero outside)
 };
 
 template <typename T> __device__ __forceinline__ int wg_swz(int pix);
@@ -542,13 +548,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         const int ty = sp % a.tiles_y;
         const int n = sp / a.tiles_y;
         const int y0 = ty * TH - PAD, x0 = tx * kTW - PAD;
+        const bool slice_ok = a.depth == 0 || (unsigned)(n % a.depth + a.kd) < (unsigned)a.depth;
         const unsigned xdst = lds0 + st * (XBYTES + DBYTES), ddst = xdst + XBYTES;
 #pragma unroll
         for (int k = 0; k < XL; ++k) {
             const int info = xinfo[k];
             const int gy = y0 + (info >> 16), gx = x0 + ((info >> 8) & 255);
-            const bool ok = info >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            const char* src = ok ? xsrc0 + ((((int64_t)n * a.H + gy) * a.W + gx) * ldx + (info & 255)) * (int64_t)sizeof(T)
+            const bool ok = info >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && slice_ok;
+            const char* src = ok ? xsrc0 + ((((int64_t)(n + a.kd) * a.H + gy) * a.W + gx) * ldx + (info & 255)) * (int64_t)sizeof(T)
                                  : reinterpret_cast<const char*>(&kZeroSlot);
             // the last transfer of the halo is partial: lanes past the image's end are masked off
             if (k * kConvThreads + tid < HPIX * 8) glds16_hidden(src, xdst + (k * kConvThreads + wave * 64) * 16);
@@ -745,7 +752,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const f
                                                                          int taps, int cin_tot, int cout_real, int cin_real,
                                                                          int seg0, int k0_pad, float* __restrict__ dw,
                                                                          int accumulate, int ct_cout, int ct_k0, int ct_k1,
-                                                                         int ct_k2, int ct_k3) {
+                                                                         int ct_k2, int ct_k3, int64_t dw_so, int64_t dw_si) {
     constexpr int OPW = 64 / P;   // outputs per wavefront
     const int64_t total = (int64_t)cout_real * cin_real * taps;
     const int lane = threadIdx.x & 63, p = lane / OPW, c = lane % OPW;
@@ -768,25 +775,26 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const f
         // ordinary convolution: OIHW [co][ci][tap].  Transposed convolution (ct_cout > 0): the weight is
         // [ci][co][4][4] and tap t of this phase is kernel element ct_k{t}.
         float* d = ct_cout > 0 ? dw + ((int64_t)ci * ct_cout + co) * 16 + (t == 0 ? ct_k0 : t == 1 ? ct_k1 : t == 2 ? ct_k2 : ct_k3)
-                               : dw + ((int64_t)co * cin_real + ci) * taps + t;
+                               : dw + co * dw_so + ci * dw_si + t;
         *d = accumulate ? *d + s : s;
     }
 }
 
 static void launch_wgrad_reduce(hipStream_t st, const float* slab, int splits, int64_t co_tot, int taps, int cin_tot, int cout_real,
                                 int cin_real, int seg0, int k0_pad, float* dw, int accumulate, int ct_cout = 0, int k0 = 0, int k1 = 0,
-                                int k2 = 0, int k3 = 0) {
+                                int k2 = 0, int k3 = 0, int64_t dw_so = 0, int64_t dw_si = 0) {
     const int64_t total = (int64_t)cout_real * cin_real * taps;
+    if (dw_so == 0) { dw_so = (int64_t)cin_real * taps; dw_si = taps; }   // contiguous OIHW
     if (splits >= 32) {
         int64_t grid = (total * 8 + kConvThreads - 1) / kConvThreads;
         if (grid > 16384) grid = 16384;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<8>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
-                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3);
+                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si);
     } else {
         int64_t grid = (total + kConvThreads - 1) / kConvThreads;
         if (grid > 8192) grid = 8192;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<1>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
-                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3);
+                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si);
     }
 }
 
@@ -919,7 +927,7 @@ extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, in
     int64_t grid = (slots + kConvThreads - 1) / kConvThreads;
     if (grid > 4096) grid = 4096;
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3((unsigned)grid), dim3(kConvThreads), 0, (hipStream_t)stream,
-                                                     w_oihw, (int)Cout, (int)Cin, taps, (int)seg0, (char*)wf, (char*)wb));
+                                                     w_oihw, (int)Cout, (int)Cin, taps, (int)seg0, (char*)wf, (char*)wb, Cin * taps, (int64_t)taps));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1142,6 +1150,109 @@ extern "C" int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t C
         SEGK_LAUNCH_CHECK();
         launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, 4, a.nch * kr, (int)Cout, (int)Cin, (int)Cin,
                             a.nch0 * kr, dw, (flags >> 1) & 1, (int)Cout, kidx[0], kidx[1], kidx[2], kidx[3]);
+        SEGK_LAUNCH_CHECK();
+    }
+    return SEGK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv3d(kernel 3, stride 1, padding 1) on volumes stored slice by slice ([N*D, H, W, C]): the sum over the three
+// depth taps of a 3x3 convolution that reads the neighbouring slice (zero beyond the volume's faces), accumulated
+// in place.  Packed images: three 2-D images, one per depth tap.
+// ------------------------------------------------------------------------------------------------
+namespace segk {
+static size_t conv3d_slice_bytes(int dtype, int64_t Cout, int64_t Cin) { return segk_conv_packed_bytes(dtype, Cout, Cin, 9, 0); }
+}
+
+extern "C" size_t segk_conv3d_packed_bytes(int dtype, int64_t Cout, int64_t Cin) { return 3 * conv3d_slice_bytes(dtype, Cout, Cin); }
+
+extern "C" int segk_conv3d_pack(const float* w, int64_t Cout, int64_t Cin, int dtype, void* wf, void* wb, int dev, void* stream) {
+    SEGK_REQUIRE(w && (wf || wb) && Cin > 0 && Cout > 0, SEGK_EINVAL, "conv3d_pack: bad arguments");
+    SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "conv3d_pack: unknown dtype");
+    SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "conv3d_pack: packed buffers must be 16-byte aligned");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    const size_t per = conv3d_slice_bytes(dtype, Cout, Cin);
+    const int64_t slots = ((wf ? round_up(Cin, kr) / kr * round_up(Cout, 32) : 0) + (wb ? round_up(Cout, kr) / kr * round_up(Cin, 32) : 0)) * 9 * 8;
+    int64_t grid = (slots + kConvThreads - 1) / kConvThreads;
+    if (grid > 4096) grid = 4096;
+    for (int kd = 0; kd < 3; ++kd) {
+        // forward image kd multiplies slice d + kd - 1; the data gradient reads dy at d - (kd - 1): its image sits at 2 - kd
+        char* f = wf ? (char*)wf + kd * per : nullptr;
+        char* b = wb ? (char*)wb + (2 - kd) * per : nullptr;
+        SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3((unsigned)grid), dim3(kConvThreads), 0, (hipStream_t)stream,
+                                                         w + kd * 9, (int)Cout, (int)Cin, 9, (int)Cin, f, b, Cin * 27, (int64_t)27));
+        SEGK_LAUNCH_CHECK();
+    }
+    return SEGK_OK;
+}
+
+extern "C" int segk_conv3d_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W,
+                               const void* w_packed, int64_t Cout, void* y, int64_t ldy, int flags, int dev, void* stream) {
+    if (int rc = check_convt("conv3d_fwd(x)", dtype, x, ldx, Cin)) return rc;
+    if (int rc = check_convt("conv3d_fwd(y)", dtype, y, ldy, Cout)) return rc;
+    SEGK_REQUIRE(w_packed && aligned16(w_packed) && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28), SEGK_ESHAPE,
+                 "conv3d_fwd: bad arguments");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    ConvArgs a;
+    a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
+    a.nch0 = a.nch = (int)(round_up(Cin, kr) / kr);
+    a.N = (int)(N * D); a.H = (int)H; a.W = (int)W; a.depth = (int)D;
+    a.vin = a.vout = identity_view((int)H, (int)W);
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
+    a.bias = nullptr; a.y = (char*)y; a.ldy = ldy; a.mask = nullptr; a.ld_mask = 0; a.mask_c = 0; a.relu = 0;
+    const int bn = pick_bn(a.cout_pad);
+    SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv3d_fwd: grid too large");
+    const size_t per = conv3d_slice_bytes(dtype, Cout, Cin);
+    // centre tap first (every slice has one, so it may overwrite); the two neighbours accumulate, and workgroups whose
+    // neighbour slice lies outside the volume exit at once
+    static const int order[3] = {1, 0, 2};
+    for (int i = 0; i < 3; ++i) {
+        const int kd = order[i];
+        a.kd = kd - 1;
+        a.w = (const char*)w_packed + kd * per;
+        a.accumulate = (i > 0 || ((flags >> 1) & 1)) ? 1 : 0;
+        launch_fwd_any(dtype, 9, a, bn, (hipStream_t)stream);
+        SEGK_LAUNCH_CHECK();
+    }
+    return SEGK_OK;
+}
+
+extern "C" size_t segk_conv3d_wgrad_workspace(int dtype, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t Cout) {
+    return segk_conv_wgrad_workspace(dtype, 9, Cin, 0, N * D, H, W, Cout);
+}
+
+extern "C" int segk_conv3d_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W,
+                                 const void* dy, int64_t ld_dy, int64_t Cout, float* dw, int flags, void* workspace,
+                                 size_t workspace_bytes, int dev, void* stream) {
+    if (int rc = check_convt("conv3d_wgrad(x)", dtype, x, ldx, Cin)) return rc;
+    if (int rc = check_convt("conv3d_wgrad(dy)", dtype, dy, ld_dy, Cout)) return rc;
+    SEGK_REQUIRE(dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28), SEGK_ESHAPE, "conv3d_wgrad: bad arguments");
+    SEGK_REQUIRE(workspace_bytes >= segk_conv3d_wgrad_workspace(dtype, Cin, N, D, H, W, Cout), SEGK_EWORKSPACE, "conv3d_wgrad: workspace too small");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a;
+    a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
+    a.nch0 = a.nch = (int)(round_up(Cin, kr) / kr);
+    a.N = (int)(N * D); a.H = (int)H; a.W = (int)W; a.depth = (int)D;
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.dy = (const char*)dy; a.ldy = ld_dy; a.Cout = (int)Cout; a.ncb = (int)((Cout + kr - 1) / kr);
+    a.vdy = identity_view((int)H, (int)W);
+    const int64_t ntiles = (int64_t)a.N * a.tiles_x * a.tiles_y;
+    a.splits = wgrad_splits(ntiles, a.ncb, a.nch);
+    a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
+    a.slab = (float*)workspace;
+    const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
+    for (int kd = 0; kd < 3; ++kd) {
+        a.kd = kd - 1;
+        launch_wgrad_any(dtype, 9, a, grid, st, Cout, Cin);
+        SEGK_LAUNCH_CHECK();
+        // dw is [Cout][Cin][3][3][3]: depth tap kd is a 9-element run inside the 27 of a (co, ci) pair
+        launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, 9, a.nch * kr, (int)Cout, (int)Cin, (int)Cin,
+                            a.nch0 * kr, dw + kd * 9, (flags >> 1) & 1, 0, 0, 0, 0, 0, Cin * 27, 27);
         SEGK_LAUNCH_CHECK();
     }
     return SEGK_OK;

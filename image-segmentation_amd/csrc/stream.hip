@@ -63,9 +63,12 @@ __global__ __launch_bounds__(kThreads) void im2col3x3_kernel(const float* __rest
 // ------------------------------------------------------------------------------ statistics
 // Block (b, g) sums its pixel range of group g for all channels.  partial layout:
 //   ws[((g*bpg + b)*2 + k)*C + c],  k = 0: sum, 1: sum of squares (or the two backward sums)
-template <typename T, int MODE>  // MODE 0: sum x, sum x^2 ; MODE 1: column sum only
+// MODE 0 sums (x - K) and (x - K)^2 with K = the group's first row (kept in kshift[g*C + c]): the variance then comes
+// from numbers of the size of the spread, not of the mean, so E[d^2] - E[d]^2 does not cancel when |mean| >> sigma
+// (few-sample BatchNorms of un-normalised features).
+template <typename T, int MODE>  // MODE 0: shifted sum, shifted sum of squares ; MODE 1: column sum only
 __global__ __launch_bounds__(kThreads) void stats_partial_kernel(const T* __restrict__ x, int64_t ld, int64_t M, int C,
-                                                                 int bpg, float* __restrict__ ws) {
+                                                                 int bpg, float* __restrict__ ws, float* __restrict__ kshift) {
     __shared__ float red[kThreads][17];
     const int cv = C / 8, rows = kThreads / cv;
     const int v = threadIdx.x % cv, r = threadIdx.x / cv;
@@ -73,14 +76,25 @@ __global__ __launch_bounds__(kThreads) void stats_partial_kernel(const T* __rest
     const int64_t per = (M + bpg - 1) / bpg;
     const int64_t lo = (int64_t)b * per, hi = (lo + per < M) ? lo + per : M;
     const T* base = x + (int64_t)g * M * ld + v * 8;
-    float s[8], q[8];
+    float s[8], q[8], kk[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = kk[j] = 0.f;
+    if (MODE == 0 && r < rows) {
+        Elem<T>::load8(base, kk);
+        if (b == 0 && r == 0) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kshift[(int64_t)g * C + v * 8 + j] = kk[j];
+        }
+    }
     for (int64_t p = lo + r; p < hi && r < rows; p += rows) {   // r >= rows: spare threads when C/8 does not divide the block
         float a[8];
         Elem<T>::load8(base + p * ld, a);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { s[j] += a[j]; if (MODE == 0) q[j] += a[j] * a[j]; }
+        for (int j = 0; j < 8; ++j) {
+            const float d = a[j] - kk[j];
+            s[j] += d;
+            if (MODE == 0) q[j] += d * d;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s[j]; red[threadIdx.x][8 + j] = q[j]; }
@@ -122,15 +136,16 @@ __device__ __forceinline__ double block_sum_partials(const float* __restrict__ w
 __global__ __launch_bounds__(kThreads) void stats_finalize_kernel(const float* __restrict__ ws, int bpg, int64_t M, int C,
                                                                   float eps, float* __restrict__ stats,
                                                                   float* __restrict__ rmean, float* __restrict__ rvar,
-                                                                  float momentum) {
+                                                                  float momentum, const float* __restrict__ kshift) {
     __shared__ double sm[4];
     const int g = blockIdx.y, c = blockIdx.x;
     const int64_t base = (int64_t)g * bpg * 2 * C + c;
     const double s = block_sum_partials(ws, base, 2 * (int64_t)C, bpg, sm);
     const double q = block_sum_partials(ws, base + C, 2 * (int64_t)C, bpg, sm);
     if (threadIdx.x != 0) return;
-    const double mean = s / (double)M;
-    double var = q / (double)M - mean * mean;
+    const double dm = s / (double)M;                       // mean of (x - K)
+    const double mean = (double)kshift[(int64_t)g * C + c] + dm;
+    double var = q / (double)M - dm * dm;
     if (var < 0.0) var = 0.0;
     stats[((int64_t)g * C + c) * 2 + 0] = (float)mean;
     stats[((int64_t)g * C + c) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
@@ -268,7 +283,7 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int relu, int frozen,
                                                                const float* __restrict__ red, T* __restrict__ dx,
-                                                               int64_t ld_dx) {
+                                                               int64_t ld_dx, int add_dx) {
     const int cv = C / 8, rows = kThreads / cv;
     const int v = threadIdx.x % cv, r = threadIdx.x / cv;
     const int g = blockIdx.y;
@@ -298,6 +313,12 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
             const float xh = (a[j] - mean[j]) * rstd[j];
             const float gg = (relu && !(pre > 0.f)) ? 0.f : d[j];
             d[j] = sc * (gg - m1[j] - xh * m2[j]);
+        }
+        if (add_dx) {
+            float o[8];
+            Elem<T>::load8(ob + p * ld_dx, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d[j] += o[j];
         }
         Elem<T>::store8(ob + p * ld_dx, d);
     }
@@ -1032,11 +1053,13 @@ extern "C" int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t gro
     SEGK_HIP(use_device(dev));
     hipStream_t st = (hipStream_t)stream;
     const int bpg = stats_bpg(groups, M, C);
+    // the per-(group, channel) shift lives in the second workspace section (the backward's reduced sums use it later)
+    float* kshift = (float*)((char*)workspace + align_up((size_t)groups * bpg * 2 * C * sizeof(float), 256));
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 0>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
-                                                     (const T*)x, ld, M, (int)C, bpg, (float*)workspace));
+                                                     (const T*)x, ld, M, (int)C, bpg, (float*)workspace, kshift));
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st,
-                       (const float*)workspace, bpg, M, (int)C, eps, stats, running_mean, running_var, momentum);
+                       (const float*)workspace, bpg, M, (int)C, eps, stats, running_mean, running_var, momentum, (const float*)kshift);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1095,7 +1118,7 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
     const int64_t gx = stream_blocks(M, rows, groups);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0, st,
                                                      (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, frozen,
-                                                     (const float*)red, (T*)dx, ld_dx));
+                                                     (const float*)red, (T*)dx, ld_dx, (flags >> 3) & 1));
     SEGK_LAUNCH_CHECK();
     if (dbias_out) {
         // With batch statistics the gradient reaching the convolution in front of the norm sums to zero
@@ -1246,7 +1269,7 @@ extern "C" int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int6
     hipStream_t st = (hipStream_t)stream;
     const int bpg = stats_bpg(1, P, C);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 1>), dim3(bpg, 1), dim3(kThreads), 0, st, (const T*)x, ld, P,
-                                                     (int)C, bpg, (float*)workspace));
+                                                     (int)C, bpg, (float*)workspace, (float*)nullptr));
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(kThreads), 0, st,
                        (const float*)workspace, bpg, (int)C, out, (flags >> 1) & 1);

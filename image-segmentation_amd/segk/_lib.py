@@ -38,6 +38,17 @@ _PROTOS = {
     "segk_convt_dgrad": (I, [I, P, L, L, L, L, L, P, L, P, L, P, L, I, I, P]),
     "segk_convt_wgrad_workspace": (Z, [I, L, L, L, L, L]),
     "segk_convt_wgrad": (I, [I, P, L, L, L, L, L, P, L, L, P, I, P, Z, I, P]),
+    "segk_conv3d_packed_bytes": (Z, [I, L, L]),
+    "segk_conv3d_pack": (I, [P, L, L, I, P, P, I, P]),
+    "segk_conv3d_fwd": (I, [I, P, L, L, L, L, L, L, P, L, P, L, I, I, P]),
+    "segk_conv3d_wgrad_workspace": (Z, [I, L, L, L, L, L, L]),
+    "segk_conv3d_wgrad": (I, [I, P, L, L, L, L, L, L, P, L, L, P, I, P, Z, I, P]),
+    "segk_im2col3d": (I, [I, P, L, L, L, L, L, L, P, P, P, P, L, L, I, P]),
+    "segk_col2im3d": (I, [I, P, L, L, L, L, L, L, P, P, P, P, L, I, I, P]),
+    "segk_maxpool3d_fwd": (I, [I, P, L, L, L, L, L, L, P, L, P, I, P]),
+    "segk_maxpool3d_bwd": (I, [I, P, L, P, L, L, L, L, L, P, L, I, I, P]),
+    "segk_avgpool3d_fwd": (I, [I, P, L, L, L, L, L, L, P, L, I, P]),
+    "segk_avgpool3d_bwd": (I, [I, P, L, L, L, L, L, L, P, L, I, I, P]),
     "segk_relu_bwd": (I, [I, P, L, P, L, L, L, P, L, I, P]),
     "segk_head1x1_fwd": (I, [I, P, L, L, L, L, P, P, L, P, I, P]),
     "segk_head1x1_bwd_workspace": (Z, [L, L, L, L]),

@@ -280,7 +280,7 @@ class Runtime:
                 da = self.grad_of(a.act) if a.ready else None
                 ops.norm_pool_bwd(da, self.grad_of(p.act), y.act, stats, gamma, beta, dy, dgamma=dg, dbeta=db, frozen=frozen)
             else:
-                ops.norm_bwd(self.grad_of(a.act), y.act, 1, stats, gamma, beta, True, dy, dgamma=dg, dbeta=db, frozen=frozen)
+                ops.norm_bwd(self.grad_of(a.act), y.act, 1, stats, gamma, beta, True, dy, dgamma=dg, dbeta=db, frozen=frozen, add_dx=y.ready)
             y.ready = True
             self._emit(prefix + ".weight", dg)
             self._emit(prefix + ".bias", db)

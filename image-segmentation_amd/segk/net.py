@@ -33,8 +33,8 @@ class _TapeFn(torch.autograd.Function):
         hooks = getattr(net, "_segk_grad_hooks", None) or (None, None, None, None)
         if not hasattr(net, "_segk_zero_grads"):
             net._segk_zero_grads = set()
-        rt = Runtime(dict(zip(names, params)), dict(net.named_buffers()), dtype, x.device, net.training, need_grad,
-                     grad_sink=hooks[0], grad_alloc=hooks[1], zero_state=net._segk_zero_grads)
+        rt = net._runtime_cls(dict(zip(names, params)), dict(net.named_buffers()), dtype, x.device, net.training, need_grad,
+                              grad_sink=hooks[0], grad_alloc=hooks[1], zero_state=net._segk_zero_grads)
         logits = net._emit(rt, x)
         rt.finish_forward()
         ctx.rt, ctx.names, ctx.hooks = rt, names, hooks
@@ -62,6 +62,7 @@ class _TapeFn(torch.autograd.Function):
 
 class SegkNet(nn.Module):
     _segk_dtype = None
+    _runtime_cls = Runtime      # tape flavour; volume networks use segk.engine3d.Runtime3D
 
     def set_compute_dtype(self, dtype):
         assert dtype in (None, torch.float32, torch.bfloat16)

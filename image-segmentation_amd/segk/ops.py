@@ -277,11 +277,13 @@ def norm_apply(x, groups, stats, gamma, beta, relu, out):
     return out
 
 
-def norm_bwd(dy, x, groups, stats, gamma, beta, relu, dx, dgamma=None, dbeta=None, dbias=None, accumulate=False, frozen=False):
+def norm_bwd(dy, x, groups, stats, gamma, beta, relu, dx, dgamma=None, dbeta=None, dbias=None, accumulate=False, frozen=False,
+             add_dx=False):
+    """accumulate: dgamma/dbeta += ...; add_dx: dx += ... (x has other consumers that already wrote their share)."""
     M = x.P // groups
     dev, st = _env(x.buf)
     ws = workspace(query("segk_norm_workspace", groups, M, x.C), x.device)
-    flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (FROZEN if frozen else 0)
+    flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (FROZEN if frozen else 0) | (8 if add_dx else 0)
     call("segk_norm_bwd", dt(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, groups, M, x.C, stats.data_ptr(), _p(gamma), _p(beta),
          flags, dx.ptr, dx.ld, _p(dgamma), _p(dbeta), _p(dbias), ws.data_ptr(), ws.numel(), dev, st)
     return dx
@@ -354,3 +356,93 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
     dev, st = _env(param)
     call("segk_adam_step", param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), lr,
          beta1, beta2, eps, weight_decay, step, grad_scale, dev, st)
+
+
+# ------------------------------------------------------------------------------------ volumes
+# A volume batch [N,C,D,H,W] is an Act over [N*D, H, W, ld]; D travels next to it.
+def _i3(t):
+    import ctypes
+    return (ctypes.c_int * 3)(*[int(v) for v in t])
+
+
+def conv3d_pack(w, dtype, want_fwd=True, want_bwd=True):
+    """fp32 Conv3d weight [Cout,Cin,3,3,3] -> (forward images, data-gradient images), one 2-D image per depth tap."""
+    Cout, Cin = w.shape[:2]
+    assert tuple(w.shape[2:]) == (3, 3, 3) and w.dtype == torch.float32 and w.is_contiguous()
+    nbytes = query("segk_conv3d_packed_bytes", dt(dtype), Cout, Cin)
+    wf = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if want_fwd else None
+    wb = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if want_bwd else None
+    dev, st = _env(w)
+    call("segk_conv3d_pack", w.data_ptr(), Cout, Cin, dt(dtype), _p(wf), _p(wb), dev, st)
+    return wf, wb
+
+
+def conv3d_fwd(x, D, w_packed, out, accumulate=False):
+    """out = Conv3d(3, padding 1)(x) with the forward images, or dx from dy with the data-gradient images."""
+    assert x.N % D == 0 and (out.N, out.H, out.W) == (x.N, x.H, x.W) and out.dtype == x.dtype
+    dev, st = _env(x.buf)
+    with _Timed("conv_fwd"):
+        call("segk_conv3d_fwd", dt(x.dtype), x.ptr, x.ld, x.C, x.N // D, D, x.H, x.W, w_packed.data_ptr(), out.C, out.ptr, out.ld,
+             ACCUM if accumulate else 0, dev, st)
+    return out
+
+
+def conv3d_wgrad(x, D, dy, dw, accumulate=False):
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.C * x.C * 27
+    dev, st = _env(x.buf)
+    d = dt(x.dtype)
+    ws = workspace(query("segk_conv3d_wgrad_workspace", d, x.C, x.N // D, D, x.H, x.W, dy.C), x.device)
+    with _Timed("conv_wgrad"):
+        call("segk_conv3d_wgrad", d, x.ptr, x.ld, x.C, x.N // D, D, x.H, x.W, dy.ptr, dy.ld, dy.C, dw.data_ptr(),
+             ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
+    return dw
+
+
+def out_extent(size, kernel, stride, pad):
+    return tuple((s + 2 * p - k) // st + 1 for s, k, st, p in zip(size, kernel, stride, pad))
+
+
+def im2col3d(x, D, C, kernel, stride, pad):
+    """Patch image of the first C channels of x: -> (Act [N*Do, Ho, Wo, Kp], Do)."""
+    N = x.N // D
+    Do, Ho, Wo = out_extent((D, x.H, x.W), kernel, stride, pad)
+    K = C * kernel[0] * kernel[1] * kernel[2]
+    Kp = (K + 7) // 8 * 8
+    out = Act.empty(N * Do, Ho, Wo, Kp, x.dtype, x.device)
+    dev, st = _env(x.buf)
+    call("segk_im2col3d", dt(x.dtype), x.ptr, x.ld, C, N, D, x.H, x.W, _i3(kernel), _i3(stride), _i3(pad), out.ptr, out.ld, Kp, dev, st)
+    return out, Do
+
+
+def col2im3d(dpatches, dx, D, C, kernel, stride, pad, accumulate=False):
+    """Adjoint of im2col3d: dx (first 8-channel group of an Act over the input volume) from the patch gradient."""
+    dev, st = _env(dx.buf)
+    call("segk_col2im3d", dt(dx.dtype), dpatches.ptr, dpatches.ld, C, dx.N // D, D, dx.H, dx.W, _i3(kernel), _i3(stride), _i3(pad),
+         dx.ptr, dx.ld, ACCUM if accumulate else 0, dev, st)
+    return dx
+
+
+def maxpool3d_fwd(x, D, out, argmax):
+    dev, st = _env(x.buf)
+    call("segk_maxpool3d_fwd", dt(x.dtype), x.ptr, x.ld, x.N // D, D, x.H, x.W, x.C, out.ptr, out.ld, argmax.data_ptr(), dev, st)
+    return out
+
+
+def maxpool3d_bwd(dy, argmax, dx, D, accumulate=False):
+    dev, st = _env(dx.buf)
+    call("segk_maxpool3d_bwd", dt(dx.dtype), dy.ptr, dy.ld, argmax.data_ptr(), dx.N // D, D, dx.H, dx.W, dx.C, dx.ptr, dx.ld,
+         ACCUM if accumulate else 0, dev, st)
+    return dx
+
+
+def avgpool3d_fwd(x, D, out):
+    dev, st = _env(x.buf)
+    call("segk_avgpool3d_fwd", dt(x.dtype), x.ptr, x.ld, x.N // D, D, x.H, x.W, x.C, out.ptr, out.ld, dev, st)
+    return out
+
+
+def avgpool3d_bwd(dy, dx, D, accumulate=False):
+    dev, st = _env(dx.buf)
+    call("segk_avgpool3d_bwd", dt(dx.dtype), dy.ptr, dy.ld, dx.N // D, D, dx.H, dx.W, dx.C, dx.ptr, dx.ld,
+         ACCUM if accumulate else 0, dev, st)
+    return dx

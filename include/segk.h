@@ -168,6 +168,54 @@ int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t
                      int64_t ld_dy, int64_t Cout, float* dw, int flags, void* workspace, size_t workspace_bytes, int dev,
                      void* stream);
 
+/* ---- volumes (the 3-D classifier of models/resnt.py:26-45 = DetectMid over models/densenet3d.py:71-159) ----------
+ * A batch of volumes [N, C, D, H, W] is stored slice by slice: [N*D, H, W, ld], channels innermost, so the
+ * channel-wise entry points above (norm_*, conv with taps=1, colsum, copy_slice) take it with N*D as the batch.
+ *
+ * Conv3d(kernel 3, stride 1, padding 1, bias=False): three 3x3 convolutions, one per depth tap, each reading the
+ * neighbouring slice of the same volume (zero beyond its faces) and accumulating in place.
+ * replaces: nn.Conv3d(bn_size*growth_rate, growth_rate, kernel_size=3, stride=1, padding=1, bias=False) forward and
+ *           backward (models/densenet3d.py:27-32).  w: the module's fp32 [Cout, Cin, 3, 3, 3] weight.
+ * segk_conv3d_fwd with the `wb` image on dy (Cout channels) yields dx (Cin channels).  flags bit1: accumulate.
+ * dw: fp32 [Cout, Cin, 3, 3, 3]; flags bit1: dw += result.                                                    */
+size_t segk_conv3d_packed_bytes(int dtype, int64_t Cout, int64_t Cin);
+int segk_conv3d_pack(const float* w, int64_t Cout, int64_t Cin, int dtype, void* wf, void* wb, int dev, void* stream);
+int segk_conv3d_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W,
+                    const void* w_packed, int64_t Cout, void* y, int64_t ldy, int flags, int dev, void* stream);
+size_t segk_conv3d_wgrad_workspace(int dtype, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t Cout);
+int segk_conv3d_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W,
+                      const void* dy, int64_t ld_dy, int64_t Cout, float* dw, int flags, void* workspace,
+                      size_t workspace_bytes, int dev, void* stream);
+
+/* Patch gather for the strided stem convolutions: patches[n,od,oh,ow, ((c*kd+a)*kh+b)*kw+e] =
+ * x[n, od*sd-pd+a, oh*sh-ph+b, ow*sw-pw+e, c] for the first C (<= 8) channels of x, zero outside the volume and in
+ * columns [C*kd*kh*kw, Kp); kernel/stride/pad are int[3] = (depth, height, width).  The column order equals a
+ * flattened Conv3d weight, so the convolution is segk_conv_fwd(taps=1) on the patches.
+ * replaces: the im2col half of nn.Conv3d(in_classes, 3, (3,7,7), stride (1,2,2), padding (1,3,3)) (models/resnt.py:30)
+ *           and nn.Conv3d(3, 64, (7,7,7), stride (1,2,2), padding (3,3,3)) (models/densenet3d.py:98-104).
+ * segk_col2im3d is its adjoint (the data gradient w.r.t. x from the patch gradient); flags bit1: accumulate.     */
+int segk_im2col3d(int dtype, const void* x, int64_t ldx, int64_t C, int64_t N, int64_t D, int64_t H, int64_t W,
+                  const int* kernel, const int* stride, const int* pad, void* patches, int64_t ld_patches, int64_t Kp,
+                  int dev, void* stream);
+int segk_col2im3d(int dtype, const void* dpatches, int64_t ld_patches, int64_t C, int64_t N, int64_t D, int64_t H, int64_t W,
+                  const int* kernel, const int* stride, const int* pad, void* dx, int64_t ld_dx, int flags, int dev,
+                  void* stream);
+
+/* MaxPool3d(kernel 3, stride 2, padding 1): [N,D,H,W,C] -> [N,(D-1)/2+1,...]; argmax receives one byte per output
+ * element (winning window position, first maximum in scan order) and drives the backward gather.
+ * replaces: nn.MaxPool3d(kernel_size=3, stride=2, padding=1) (models/densenet3d.py:107-109).  flags bit1: accumulate. */
+int segk_maxpool3d_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t D, int64_t H, int64_t W, int64_t C,
+                       void* y, int64_t ldy, unsigned char* argmax, int dev, void* stream);
+int segk_maxpool3d_bwd(int dtype, const void* dy, int64_t ld_dy, const unsigned char* argmax, int64_t N, int64_t D,
+                       int64_t H, int64_t W, int64_t C, void* dx, int64_t ld_dx, int flags, int dev, void* stream);
+
+/* AvgPool3d(kernel 2, stride 2) and its backward.
+ * replaces: nn.AvgPool3d(kernel_size=2, stride=2) of the transitions (models/densenet3d.py:68).                  */
+int segk_avgpool3d_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t D, int64_t H, int64_t W, int64_t C,
+                       void* y, int64_t ldy, int dev, void* stream);
+int segk_avgpool3d_bwd(int dtype, const void* dy, int64_t ld_dy, int64_t N, int64_t D, int64_t H, int64_t W, int64_t C,
+                       void* dx, int64_t ld_dx, int flags, int dev, void* stream);
+
 /* 1x1 head: logits[n,co,y,x] (NCHW fp32) = bias[co] + sum_ci x[n,y,x,ci]*w[co,ci].
  * replaces: models/unetvgg.py:88,105 (final = Conv2d(32,C,1)); models/unetplusplus.py:58,81.      */
 int segk_head1x1_fwd(int dtype, const void* x, int64_t ld, int64_t Cin, int64_t N, int64_t HW, const float* w,
@@ -208,7 +256,8 @@ int segk_norm_eval_stats(const float* running_mean, const float* running_var, in
 /* Backward of y = act(norm(x)):  g = dy * (y_pre>0 if ReLU);  dgamma = sum g*xhat, dbeta = sum g,
  * dx = gamma*rstd*(g - mean(g) - xhat*mean(g*xhat)).  Two launches inside: reduce, then dx.
  * dgamma/dbeta (fp32 [C], BatchNorm only) may be NULL; dx may alias dy.  flags bit0: ReLU,
- * bit1: dgamma/dbeta += .   dbias_out (optional fp32 [C]): column sum of dx (bias gradient of the
+ * bit1: dgamma/dbeta += , bit2: frozen (running) statistics, bit3: dx += (x has other consumers whose share is
+ * already in dx; dx must then not alias dy).   dbias_out (optional fp32 [C]): column sum of dx (bias gradient of the
  * convolution in front of the norm).
  * replaces: autograd backward of batch_norm / instance_norm + ReLU.                                */
 int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const void* x, int64_t ldx, int64_t groups,

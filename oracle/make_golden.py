@@ -42,7 +42,7 @@ torch.manual_seed(20)
 def import_reference():
     import importlib
     mods = {}
-    for name in ("models.unetvgg", "models.unetplusplus", "loss.dice", "loss.focal"):
+    for name in ("models.unetvgg", "models.unetplusplus", "models.resnt", "models.densenet3d", "loss.dice", "loss.focal"):
         mods[name] = importlib.import_module(name)
         assert mods[name].__file__.startswith(REF), mods[name].__file__
     return mods
@@ -188,12 +188,72 @@ def golden_models(ref, pin):
         json.dump(keys, f, indent=0)
 
 
+# ------------------------------------------------------------------------------------ 3-D classifier
+# (2, 32, 128) volumes leave 2x2x2 voxels x 2 volumes = 16 samples per channel for the last block's BatchNorms; with
+# fewer (a 16x64x64 volume ends at ONE voxel, 2 samples) the network is chaotic: the reference's own fp32 and fp64 runs
+# then disagree by 30 % on the output, so such a case pins nothing.
+VOLUME_CASES = [("detectmid", dict(), (2, 32, 128)), ("detectmid_regr", dict(if_regr=True, out_classes=1), (2, 32, 128))]
+
+
+def golden_volumes(ref, pin):
+    """DetectMid (models/resnt.py:8-45) on synthetic volumes with the loss of train_midlslice.py:29 (cross entropy on
+    the 80 slice classes); the regression variant with an MSE loss on the squeezed output."""
+    resnt = ref["models.resnt"]
+    out, keys = {}, {}
+    for name, kw, (n, depth, side) in VOLUME_CASES:
+        x, t = RM.synthetic_volumes(n, depth, side, tag=f"model:{name}")
+        m_ref = RM.hash_init_(resnt.DetectMid(in_classes=1, **kw))
+        m_or = RM.hash_init_(RM.RefDetectMid(in_classes=1, **kw))
+        assert list(m_ref.state_dict().keys()) == list(m_or.state_dict().keys()), name
+        keys[name] = {k: list(v.shape) for k, v in m_ref.state_dict().items()}
+        res = []
+        for m in (m_ref, m_or):
+            m.train()
+            m.zero_grad()
+            y = m(x)
+            loss = torch.nn.functional.mse_loss(y, t.float() / 80) if kw.get("if_regr") else torch.nn.functional.cross_entropy(y, t)
+            loss.backward()
+            res.append((y.detach(), loss.detach()))
+        same = bits_equal(res[0][0], res[1][0]) and bits_equal(res[0][1], res[1][1])
+        for (ka, pa), (_, pb) in zip(m_ref.named_parameters(), m_or.named_parameters()):
+            same = same and ((pa.grad is None and pb.grad is None) or bits_equal(pa.grad, pb.grad))
+        for (ka, ba), (_, bb) in zip(m_ref.named_buffers(), m_or.named_buffers()):
+            same = same and bits_equal(ba, bb)
+        pin[f"model/{name}"] = bool(same)
+        out[f"{name}/out"] = res[0][0].numpy()
+        out[f"{name}/loss"] = res[0][1].numpy()
+        for k, p_ in m_ref.named_parameters():
+            if p_.grad is None:
+                continue
+            g = p_.grad.flatten()
+            out[f"{name}/grad_norm/{k}"] = np.float64(g.double().norm().item())
+            out[f"{name}/grad_head/{k}"] = g[:16].numpy().copy()
+        for k, b in m_ref.named_buffers():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                out[f"{name}/bufsum/{k}"] = np.float64(b.double().sum().item())
+        m_ref.eval()
+        with torch.no_grad():
+            out[f"{name}/eval_out"] = m_ref(x).numpy()
+    np.savez_compressed(os.path.join(GOLD, "volumes.npz"), **out)
+    kf = os.path.join(GOLD, "state_dict_keys.json")
+    allkeys = json.load(open(kf)) if os.path.exists(kf) else {}
+    allkeys.update(keys)
+    with open(kf, "w") as f:
+        json.dump(allkeys, f, indent=0)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
     pin = {}
-    golden_losses(ref, pin)
-    golden_models(ref, pin)
+    if "--volumes-only" in sys.argv:      # refresh the 3-D fixtures without regenerating the 2-D ones
+        pf = os.path.join(GOLD, "oracle_pin.json")
+        pin = json.load(open(pf))["checks"] if os.path.exists(pf) else {}
+        golden_volumes(ref, pin)
+    else:
+        golden_losses(ref, pin)
+        golden_models(ref, pin)
+        golden_volumes(ref, pin)
     verdict = {"torch": torch.__version__, "numpy": np.__version__, "all_bitwise_equal": all(pin.values()), "checks": pin}
     with open(os.path.join(GOLD, "oracle_pin.json"), "w") as f:
         json.dump(verdict, f, indent=1, sort_keys=True)

@@ -5,6 +5,8 @@ Plain `torch.nn` restatement of the two graded networks with the reference's sta
 * VGG16-BN encoder + five-stage decoder -- /root/reference/models/unetvgg.py:6-41 (decoder block),
   :52-105 (UNetVgg), :158-213 (UNetVggInOut)
 * nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
+* 3-D DenseNet-BC classifier + DetectMid -- /root/reference/models/densenet3d.py:10-159, 162-186;
+                                           /root/reference/models/resnt.py:8-45
 
 Pinned by `oracle/make_golden.py` (bitwise equality with the imported reference in the build
 container).  Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import it.
@@ -118,6 +120,91 @@ class RefNestedUNet(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # Deterministic, torch-RNG-independent initialiser shared by the oracle, the tests and the fixtures
 # ---------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------------
+# 3-D DenseNet-BC (densenet3d.py) and the middle-slice detector on top of it (resnt.py:8-45)
+# ---------------------------------------------------------------------------------------------------
+def _bn_relu_conv3d(c_in, c_out, k, names):
+    """BatchNorm3d -> ReLU -> Conv3d(bias=False, 'same' padding) under the given three child names."""
+    return [(names[0], nn.BatchNorm3d(c_in)), (names[1], nn.ReLU(inplace=True)),
+            (names[2], nn.Conv3d(c_in, c_out, kernel_size=k, stride=1, padding=k // 2, bias=False))]
+
+
+class _RefDenseLayer(nn.Sequential):
+    """densenet3d.py:10-41: bottleneck 1x1x1 to bn_size*growth channels, 3x3x3 to growth channels, concat with the input."""
+
+    def __init__(self, c_in, growth, bn_size):
+        super().__init__(OrderedDict(_bn_relu_conv3d(c_in, bn_size * growth, 1, ("norm1", "relu1", "conv1")) +
+                                     _bn_relu_conv3d(bn_size * growth, growth, 3, ("norm2", "relu2", "conv2"))))
+
+    def forward(self, x):
+        return torch.cat([x, super().forward(x)], 1)
+
+
+class RefDenseNet3D(nn.Module):
+    """densenet3d.py:71-159 with drop_rate=0 (the reference default; DetectMid never changes it)."""
+
+    def __init__(self, n_input_channels=3, conv1_t_size=7, conv1_t_stride=1, no_max_pool=False, growth_rate=32,
+                 block_config=(6, 12, 24, 16), num_init_features=64, bn_size=4, num_classes=1000):
+        super().__init__()
+        stem = OrderedDict()
+        stem["conv1"] = nn.Conv3d(n_input_channels, num_init_features, kernel_size=(conv1_t_size, 7, 7),
+                                  stride=(conv1_t_stride, 2, 2), padding=(conv1_t_size // 2, 3, 3), bias=False)
+        stem["norm1"] = nn.BatchNorm3d(num_init_features)
+        stem["relu1"] = nn.ReLU(inplace=True)
+        if not no_max_pool:
+            stem["pool1"] = nn.MaxPool3d(kernel_size=3, stride=2, padding=1)
+        self.features = nn.Sequential(stem)
+        c = num_init_features
+        for b, n_layers in enumerate(block_config, start=1):
+            block = nn.Sequential(OrderedDict((f"denselayer{j + 1}", _RefDenseLayer(c + j * growth_rate, growth_rate, bn_size))
+                                              for j in range(n_layers)))
+            self.features.add_module(f"denseblock{b}", block)
+            c += n_layers * growth_rate
+            if b != len(block_config):
+                trans = nn.Sequential(OrderedDict(_bn_relu_conv3d(c, c // 2, 1, ("norm", "relu", "conv")) +
+                                                  [("pool", nn.AvgPool3d(kernel_size=2, stride=2))]))
+                self.features.add_module(f"transition{b}", trans)
+                c //= 2
+        self.features.add_module("norm5", nn.BatchNorm3d(c))
+        self.classifier = nn.Linear(c, num_classes)
+
+    def forward(self, x):
+        f = self.features(x)
+        out = torch.nn.functional.relu(f, inplace=True)
+        out = torch.nn.functional.adaptive_avg_pool3d(out, output_size=(1, 1, 1)).view(f.size(0), -1)
+        return self.classifier(out)
+
+
+_DENSE_CONFIGS = {121: (6, 12, 24, 16), 169: (6, 12, 32, 32), 201: (6, 12, 48, 32), 264: (6, 12, 64, 48)}
+
+
+class RefDetectMid(nn.Module):
+    """resnt.py:8-45: Conv3d(in_classes, 3, (3,7,7), stride (1,2,2)) -> DenseNet-169 (3-D) -> Linear(1000, 80)
+    (-> Linear(80, out_classes), squeezed, when if_regr)."""
+
+    def __init__(self, in_classes=1, out_classes=1, if_regr=False, model_depth=169):
+        super().__init__()
+        self.rsnet = RefDenseNet3D(block_config=_DENSE_CONFIGS[model_depth])
+        self.patch_train = False
+        self.first = nn.Conv3d(in_classes, 3, kernel_size=(3, 7, 7), stride=(1, 2, 2), padding=(1, 3, 3), bias=False)
+        self.last = nn.Linear(1000, 80)
+        self.lastregr = nn.Linear(80, out_classes)
+        self.if_regr = if_regr
+
+    def forward(self, x):
+        out = self.last(self.rsnet(self.first(x)))
+        if self.if_regr:
+            out = self.lastregr(out).squeeze(dim=-1)
+        return out
+
+
+def synthetic_volumes(n, depth, side, tag="vol"):
+    """Z-scored single-channel volumes and a middle-slice class per volume (< 80, train_midlslice.py:25-33)."""
+    x = hash_uniform(tag + ":vol", (n, 1, depth, side, side), -1.7320508, 1.7320508)
+    t = (hash_uniform(tag + ":mid", (n,), 0.0, 1.0) * min(depth, 80)).long().clamp_(0, 79)
+    return x, t
+
+
 def _splitmix64(x):
     import numpy as np
     x = (x + np.uint64(0x9E3779B97F4A7C15))
@@ -153,9 +240,12 @@ def hash_init_(module, salt="w"):
             t.copy_(hash_uniform(tag, t.shape, -0.1, 0.1))
         elif key.endswith("running_var"):
             t.copy_(hash_uniform(tag, t.shape, 0.8, 1.2))
-        elif t.dim() == 4:
-            fan_in = t.shape[1] * t.shape[2] * t.shape[3]
+        elif t.dim() in (4, 5):
+            fan_in = t[0].numel()
             bound = (6.0 / fan_in) ** 0.5      # He-uniform keeps activations O(1) through ReLU stacks
+            t.copy_(hash_uniform(tag, t.shape, -bound, bound))
+        elif t.dim() == 2:                     # nn.Linear
+            bound = (3.0 / t.shape[1]) ** 0.5
             t.copy_(hash_uniform(tag, t.shape, -bound, bound))
         elif key.endswith("weight"):           # BN gamma
             t.copy_(hash_uniform(tag, t.shape, 0.75, 1.25))

@@ -2,6 +2,7 @@
 (new Adam per epoch, validation every `valid_after` epochs, checkpoint dict) on synthetic slices."""
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -81,4 +82,36 @@ def test_train_general_gpu(tmp_path):
         a = cpu_model.eval()(x)
         model.load_state_dict(state["state_dict"])
         b = model.eval()(x.cuda()).cpu()
+    assert float((a - b).norm() / a.norm()) < 1e-3
+
+
+@pytest.mark.gpu
+def test_mid_slice_training_gpu(tmp_path):
+    """The call of train_midlslice.py:25-33 (DetectMid, CrossEntropyLoss, naive loop, sgm_train=False) on stand-in
+    volumes: the HIP path trains, writes the reference's checkpoint layout, and the checkpoint loads into a CPU model."""
+    from torch import nn
+    from data_read.read_3dinput import Meniscus3DMidSlice
+    from models.resnt import DetectMid
+    from segk import _lib
+    from train_helper.common import train_general
+    torch.manual_seed(20)
+    dataset = Meniscus3DMidSlice("/nonexistent", num_img=10, in_channels=1, depth=32, side=128)
+    model = DetectMid(in_classes=1)
+    before = _lib.launches
+    out = train_general(dataset, str(tmp_path), expt_name="train_midlsl", val_set_perc=0.2, device=torch.device("cuda"), num_epochs=3,
+                        is_naive_train=True, valid_after=1, net_model=model, batch_size=4, test_set_perc=0.0,
+                        loss_criterion=[nn.CrossEntropyLoss()], val_acc_func=nn.CrossEntropyLoss(), sgm_train=False, test_batch_size=1,
+                        lr=1e-4)
+    m = out.segk_metrics
+    assert _lib.launches - before > 5000, "the HIP library did not run the training loop"
+    assert all(np.isfinite(v) for v in m["train_loss"]) and m["train_loss"][-1] < m["train_loss"][0]
+    names = [n for n in os.listdir(tmp_path) if "epoch" in n]
+    assert len(names) == 1
+    state = torch.load(os.path.join(tmp_path, names[0]), weights_only=True)
+    cpu_model = DetectMid(in_classes=1)
+    cpu_model.load_state_dict(state["state_dict"], strict=True)
+    x, _ = dataset[0]
+    with torch.no_grad():
+        a = cpu_model.eval()(x[None])
+        b = out.eval()(x[None].cuda()).cpu()
     assert float((a - b).norm() / a.norm()) < 1e-3

@@ -75,6 +75,8 @@ def _product(name):
         "unetvgg_c4_convtrans": lambda: UNetVgg(out_classes=4, if_convtrans=True),
         "unetvgginout_c4": lambda: UNetVggInOut(in_classes=1, out_classes=4),
         "nestedunet_c4": lambda: Nested_UNet(in_ch=1, out_ch=4),
+        "detectmid": lambda: __import__("models.resnt", fromlist=["DetectMid"]).DetectMid(in_classes=1),
+        "detectmid_regr": lambda: __import__("models.resnt", fromlist=["DetectMid"]).DetectMid(in_classes=1, if_regr=True, out_classes=1),
     }[name]()
 
 
@@ -86,10 +88,12 @@ def _oracle(name):
         "unetvgg_c4_convtrans": lambda: RM.RefUNetVgg(out_classes=4, if_convtrans=True),
         "unetvgginout_c4": lambda: RM.RefUNetVgg(out_classes=4, in_classes=1),
         "nestedunet_c4": lambda: RM.RefNestedUNet(in_ch=1, out_ch=4),
+        "detectmid": lambda: RM.RefDetectMid(in_classes=1),
+        "detectmid_regr": lambda: RM.RefDetectMid(in_classes=1, if_regr=True, out_classes=1),
     }[name]()
 
 
-ALL = ["unetvgg_c4", "unetvgg_c3", "unetvgg_c4_convtrans", "unetvgginout_c4", "nestedunet_c4"]
+ALL = ["unetvgg_c4", "unetvgg_c3", "unetvgg_c4_convtrans", "unetvgginout_c4", "nestedunet_c4", "detectmid", "detectmid_regr"]
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -132,6 +136,27 @@ def test_oracle_and_host_path_match_golden(name, golden):
         report(k, a.grad, b.grad, rtol=1e-3, atol=1e-5)
 
 
+def test_detectmid_host_path_matches_oracle():
+    """3-D classifier on CPU tensors (plain torch.nn modules holding the parameters): one small train step equals the
+    oracle's (which make_golden.py pinned bit for bit to the reference's models/resnt.py + models/densenet3d.py)."""
+    import torch.nn.functional as F
+    from oracle.ref_models import RefDetectMid, hash_init_, synthetic_volumes
+    from models.resnt import DetectMid
+    x, t = synthetic_volumes(2, 16, 64, tag="model:host")
+    torch.set_num_threads(8)
+    outs = []
+    for mk in (RefDetectMid, DetectMid):
+        m = hash_init_(mk(in_classes=1)).train()
+        y = m(x)
+        F.cross_entropy(y, t).backward()
+        outs.append((y.detach(), {k: p.grad for k, p in m.named_parameters()}, dict(m.named_buffers())))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k, g in outs[0][1].items():
+        assert (g is None and outs[1][1][k] is None) or torch.equal(g, outs[1][1][k]), k
+    for k, b in outs[0][2].items():
+        assert torch.equal(b, outs[1][2][k]), k
+
+
 def test_constructor_surface():
     from models.unetvgg import UNetVgg, UNetVggInOut, make_decoder_block
     from models.unetplusplus import Nested_UNet, conv_block_nested
@@ -148,6 +173,14 @@ def test_constructor_surface():
     assert conv_block_nested(3, 8, 8)(torch.zeros(2, 3, 4, 4)).shape == (2, 8, 4, 4)
     with pytest.raises(RuntimeError, match="pretrained"):
         UNetVgg(pretrained=True)
+    from models.densenet3d import generate_model
+    from models.resnt import DetectMid
+    d = DetectMid(in_classes=2, out_classes=3)
+    assert d.first.in_channels == 2 and d.last.out_features == 80 and d.lastregr.out_features == 3 and d.patch_train is False
+    assert len(d.rsnet.features.denseblock3) == 32 and d.rsnet.classifier.in_features == 1664
+    assert generate_model(121).classifier.in_features == 1024
+    with pytest.raises(AssertionError):
+        generate_model(50)
 
 
 def test_gpu_tensors_never_fall_back(monkeypatch):
