@@ -43,6 +43,24 @@ def synthetic(batch, side, n_classes, device, seed=20):
     return x.to(device), t.to(device)
 
 
+def detectmid_gflop(model, depth, side):
+    """Convolution GFLOP per volume of DetectMid (fwd + dgrad + wgrad, 2 FLOP/MAC, no dgrad on the first convolution)."""
+    d, h, w = depth, side // 2, side // 2                       # after `first` (stride 1,2,2)
+    macs = model.first.weight.numel() * d * h * w               # counted 2x below (fwd + wgrad)
+    total = 2 * 2 * macs
+    h, w = h // 2, w // 2                                       # after the DenseNet stem (stride 1,2,2)
+    total += 3 * 2 * model.rsnet.features.conv1.weight.numel() * d * h * w
+    d, h, w = (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1   # MaxPool3d(3, 2, 1)
+    for name, mod in model.rsnet.features.named_children():
+        if name.startswith("denseblock"):
+            for layer in mod.children():
+                total += 3 * 2 * (layer.conv1.weight.numel() + layer.conv2.weight.numel()) * d * h * w
+        elif name.startswith("transition"):
+            total += 3 * 2 * mod.conv.weight.numel() * d * h * w
+            d, h, w = d // 2, h // 2, w // 2
+    return total / 1e9
+
+
 def cpu_baseline(n_classes, seconds_budget=25.0):
     """The CPU oracle (plain torch.nn restatement pinned to the reference) on configs[0]: N=4, fp32, fwd+loss+bwd."""
     from oracle import ref_losses as RL
@@ -69,6 +87,25 @@ def cpu_baseline(n_classes, seconds_budget=25.0):
             "sample": f"oracle RefUNetVgg fp32, batch 4 x 3x384x384, fwd+loss+bwd, median of {len(steady)} steps after 1 warm-up"}
 
 
+def cpu_baseline_detectmid(depth, side):
+    """The CPU oracle of the 3-D classifier (RefDetectMid, pinned to the reference) on ONE volume, fp32, fwd+loss+bwd."""
+    from oracle.ref_models import RefDetectMid
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    torch.manual_seed(20)
+    model = RefDetectMid(in_classes=1).train()
+    x = torch.randn(2, 1, depth, side, side)       # BatchNorm needs more than one value per channel at the last stage
+    t = torch.tensor([depth // 2, depth // 3])
+    times = []
+    for _ in range(2):
+        t0 = time.perf_counter()
+        model.zero_grad()
+        torch.nn.functional.cross_entropy(model(x), t).backward()
+        times.append(time.perf_counter() - t0)
+    return {"value": round(2 / times[-1], 4), "unit": "volumes/s", "cores": threads, "kind": "port",
+            "sample": f"oracle RefDetectMid fp32, batch 2 x 1x{depth}x{side}x{side}, fwd+loss+bwd, second of 2 steps"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,7 +114,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="slices per GPU")
     ap.add_argument("--side", type=int, default=384)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp"])
+    ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid"])
+    ap.add_argument("--depth", type=int, default=64, help="slices per volume (detectmid)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -106,7 +144,16 @@ def main():
 
     n_classes = 4
     torch.manual_seed(20)
-    if args.model == "unetpp":
+    if args.model == "detectmid":
+        # BASELINE.json configs[4]: 3-D DenseNet-169 middle-slice classifier on 64 x 256 x 256 volumes
+        from models.resnt import DetectMid
+        model = DetectMid(in_classes=1)
+        if args.side == 384:
+            args.side = 256
+        if args.batch == 32:
+            args.batch = 4
+        gflop = detectmid_gflop(model, args.depth, args.side)
+    elif args.model == "unetpp":
         from models.unetplusplus import Nested_UNet
         model = Nested_UNet(in_ch=1, out_ch=n_classes)
         gflop = 1859.61
@@ -117,13 +164,21 @@ def main():
     model = model.to(device).train().set_compute_dtype(dtype)
     flat = FlatModel(model)                    # flat params/grads; bucketed all-reduce when world > 1
     opt = Adam(flat, lr=1e-4)
-    x, t = synthetic(args.batch, args.side, n_classes, device, seed=20 + rank)
+    if args.model == "detectmid":
+        g = torch.Generator().manual_seed(20 + rank)
+        x = torch.randn(args.batch, 1, args.depth, args.side, args.side, generator=g).to(device)
+        t = torch.randint(0, min(args.depth, 80), (args.batch,), generator=g).to(device)
+    else:
+        x, t = synthetic(args.batch, args.side, n_classes, device, seed=20 + rank)
     if args.model == "unetpp":
         x = x[:, :1].contiguous()
 
     def step():
         logits = model(x)
-        loss = dice_loss_sq(logits, t) + focal_loss_with_logits(logits, t)
+        if args.model == "detectmid":
+            loss = torch.nn.functional.cross_entropy(logits, t)      # train_midlslice.py:29
+        else:
+            loss = dice_loss_sq(logits, t) + focal_loss_with_logits(logits, t)
         loss.backward()
         opt.step()
         return loss
@@ -154,12 +209,16 @@ def main():
         ms = 1e3 * elapsed / args.steps
         value = world * args.batch * args.steps / elapsed
         out = {
-            "metric": "train slices/sec (fwd+bwd+loss) " + {"unetvgg": "UNet-VGG", "unetvgg_convtrans": "UNet-VGG (transposed-conv decoder)",
-                                                              "unetpp": "UNet++"}[args.model] + f" {args.side}x{args.side}", "value": round(value, 2), "unit": "slices/s",
+            "metric": ("train volumes/sec (fwd+bwd+loss) DenseNet3D-169 DetectMid " + f"{args.depth}x{args.side}x{args.side}") if args.model == "detectmid" else
+                      "train slices/sec (fwd+bwd+loss) " + {"unetvgg": "UNet-VGG", "unetvgg_convtrans": "UNet-VGG (transposed-conv decoder)",
+                                                              "unetpp": "UNet++"}[args.model] + f" {args.side}x{args.side}",
+            "value": round(value, 2), "unit": "volumes/s" if args.model == "detectmid" else "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.side}x{args.side}, {n_classes} classes, {args.batch} slices/GPU, "
-                                   f"fwd + fused Dice/focal loss + bwd + {'bucketed RCCL all-reduce + ' if world > 1 else ''}fused Adam",
+            "config": {"workload": (f"detectmid {args.depth}x{args.side}x{args.side}, 80 classes, {args.batch} volumes/GPU, fwd + cross entropy + bwd + "
+                                    if args.model == "detectmid" else
+                                    f"{args.model} {args.side}x{args.side}, {n_classes} classes, {args.batch} slices/GPU, fwd + fused Dice/focal loss + bwd + ")
+                                   + f"{'bucketed RCCL all-reduce + ' if world > 1 else ''}fused Adam",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "random_init_weights": True,
                        "final_loss": round(final_loss, 5)},
         }
@@ -172,7 +231,7 @@ def main():
             # HBM bytes of the same launches (one step) from the committed PMC passes of this workload; null for other workloads
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-            if args.model == "unetvgg" and args.dtype == "bf16" and args.batch == 32 and args.side == 384 and os.path.exists(tfile):
+            if args.model == "unetvgg" and args.dtype == "bf16" and args.batch == 32 and args.side == 384 and os.path.exists(tfile):  # noqa: E501
                 with open(tfile) as f:
                     traffic = json.load(f).get("conv_mfma_kernels_hbm_bytes_per_step")
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
@@ -184,7 +243,7 @@ def main():
                                "fwd_dgrad_ms": round(fwd / args.steps, 3), "wgrad_ms": round(wg / args.steps, 3),
                                "whole_step_mfma_frac": round(gflop * args.batch / ms / peak, 4)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n_classes)
+            out["cpu_baseline"] = cpu_baseline_detectmid(args.depth, args.side) if args.model == "detectmid" else cpu_baseline(n_classes)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

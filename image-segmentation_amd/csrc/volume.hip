@@ -24,9 +24,10 @@ struct Geo3 {
 };
 
 // ------------------------------------------------------------------------------------------------
-// patches[n, od, oh, ow, ((c*kd + a)*kh + b)*kw + e] = x[n, od*sd - pd + a, oh*sh - ph + b, ow*sw - pw + e, c]
-// (zero outside the volume and in the padding columns behind K = C*kd*kh*kw): the column order is that of a
-// flattened Conv3d weight [Cout, C, kd, kh, kw], so the strided convolution becomes a 1x1 convolution.
+// patches[n, od, oh, ow, ((a*kh + b)*kw + e)*C + c] = x[n, od*sd - pd + a, oh*sh - ph + b, ow*sw - pw + e, c]
+// (zero outside the volume and in the padding columns behind K = C*kd*kh*kw): tap-major, channel-minor columns, i.e.
+// a Conv3d weight permuted to [Cout, kd, kh, kw, C] and flattened, so the strided convolution becomes a 1x1
+// convolution and the channels of one tap are contiguous both in x and in the patch row.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(kVThreads) void im2col3d_kernel(const T* __restrict__ x, int64_t ldx, Geo3 g, T* __restrict__ out,
@@ -47,10 +48,10 @@ __global__ __launch_bounds__(kVThreads) void im2col3d_kernel(const T* __restrict
             int k = gr * 8 + j;
             float val = 0.f;
             if (k < K) {
+                const int c = k % g.C; k /= g.C;
                 const int e = k % g.kw; k /= g.kw;
-                const int b = k % g.kh; k /= g.kh;
-                const int a = k % g.kd;
-                const int c = k / g.kd;
+                const int b = k % g.kh;
+                const int a = k / g.kh;
                 const int d = od * g.sd - g.pd + a, y = oh * g.sh - g.ph + b, xx = ow * g.sw - g.pw + e;
                 if ((unsigned)d < (unsigned)g.D && (unsigned)y < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
                     val = Elem<T>::to_f(x[(((n * g.D + d) * g.H + y) * g.W + xx) * ldx + c]);
@@ -62,12 +63,15 @@ __global__ __launch_bounds__(kVThreads) void im2col3d_kernel(const T* __restrict
 }
 
 // Adjoint of the gather: dx[n, d, y, x, c] = sum over the patches that contain the voxel.  One thread per input voxel
-// produces its (<= 8) channels; the walk over (a, b, e) visits only taps whose output coordinate is integral.
-template <typename T>
+// produces its (<= 8) channels.  Along each axis the taps that reach an integral output coordinate are k0, k0 + s,
+// k0 + 2s, ...: the two innermost axes are walked in steps of the stride with a compile-time bound (MAXT taps per
+// axis), all loads of one depth tap predicated instead of branched, so that a thread has MAXT*MAXT*C independent
+// loads in flight instead of one at a time (the kernel is latency-bound: every element of the patch gradient is
+// read exactly once, by a different thread than its neighbours in memory).
+template <typename T, int MAXT>
 __global__ __launch_bounds__(kVThreads) void col2im3d_kernel(const T* __restrict__ dcol, int64_t ldo, Geo3 g, T* __restrict__ dx,
                                                              int64_t ldx, int accumulate) {
     const int64_t items = (int64_t)g.N * g.D * g.H * g.W;
-    const int taps = g.kd * g.kh * g.kw;
     for (int64_t i = (int64_t)blockIdx.x * kVThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kVThreads) {
         int64_t p = i;
         const int xx = (int)(p % g.W); p /= g.W;
@@ -77,25 +81,28 @@ __global__ __launch_bounds__(kVThreads) void col2im3d_kernel(const T* __restrict
         float acc[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        // first tap along h / w with (coordinate + pad - tap) divisible by the stride
+        const int b0 = (y + g.ph) % g.sh, e0 = (xx + g.pw) % g.sw;
         for (int a = 0; a < g.kd; ++a) {
             const int td = d + g.pd - a;
             if (td < 0 || td % g.sd) continue;
             const int od = td / g.sd;
             if (od >= g.Do) continue;
-            for (int b = 0; b < g.kh; ++b) {
-                const int th = y + g.ph - b;
-                if (th < 0 || th % g.sh) continue;
-                const int oh = th / g.sh;
-                if (oh >= g.Ho) continue;
-                for (int e = 0; e < g.kw; ++e) {
-                    const int tw = xx + g.pw - e;
-                    if (tw < 0 || tw % g.sw) continue;
-                    const int ow = tw / g.sw;
-                    if (ow >= g.Wo) continue;
-                    const T* src = dcol + (((n * g.Do + od) * g.Ho + oh) * g.Wo + ow) * ldo + (a * g.kh + b) * g.kw + e;
+            const T* slab = dcol + ((n * g.Do + od) * g.Ho) * (int64_t)g.Wo * ldo + (int64_t)a * g.kh * g.kw * g.C;
+#pragma unroll
+            for (int jb = 0; jb < MAXT; ++jb) {
+                const int b = b0 + jb * g.sh;
+                const int oh = (y + g.ph - b) / g.sh;            // exact by construction of b0
+                const bool okb = b < g.kh && y + g.ph - b >= 0 && oh < g.Ho;
+#pragma unroll
+                for (int je = 0; je < MAXT; ++je) {
+                    const int e = e0 + je * g.sw;
+                    const int ow = (xx + g.pw - e) / g.sw;
+                    const bool ok = okb && e < g.kw && xx + g.pw - e >= 0 && ow < g.Wo;
+                    const T* src = slab + ((int64_t)(ok ? oh : 0) * g.Wo + (ok ? ow : 0)) * ldo + ((ok ? b : 0) * g.kw + (ok ? e : 0)) * g.C;
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        if (c < g.C) acc[c] += Elem<T>::to_f(src[c * taps]);
+                        if (c < g.C) acc[c] += ok ? Elem<T>::to_f(src[c]) : 0.f;
                 }
             }
         }
@@ -334,8 +341,15 @@ extern "C" int segk_col2im3d(int dtype, const void* dpatches, int64_t ld_patches
     SEGK_REQUIRE(dpatches && ld_patches >= C * g.kd * g.kh * g.kw, SEGK_ESHAPE, "col2im3d: bad patch gradient");
     SEGK_HIP(use_device(dev));
     const int64_t items = (int64_t)g.N * g.D * g.H * g.W;
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im3d_kernel<T>), dim3(vgrid(items, 65536)), dim3(kVThreads), 0, (hipStream_t)stream,
-                                                     (const T*)dpatches, ld_patches, g, (T*)dx, ld_dx, (flags >> 1) & 1));
+    // taps per axis that can reach one voxel: ceil(kernel / stride) over the two inner axes
+    const int th = (g.kh + g.sh - 1) / g.sh, tw = (g.kw + g.sw - 1) / g.sw, mt = th > tw ? th : tw;
+    SEGK_REQUIRE(mt <= 8, SEGK_ESHAPE, "col2im3d: more than 8 taps per axis reach one voxel (kernel/stride too large)");
+    if (mt <= 4)
+        SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im3d_kernel<T, 4>), dim3(vgrid(items, 65536)), dim3(kVThreads), 0, (hipStream_t)stream,
+                                                         (const T*)dpatches, ld_patches, g, (T*)dx, ld_dx, (flags >> 1) & 1));
+    else
+        SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((col2im3d_kernel<T, 8>), dim3(vgrid(items, 65536)), dim3(kVThreads), 0, (hipStream_t)stream,
+                                                         (const T*)dpatches, ld_patches, g, (T*)dx, ld_dx, (flags >> 1) & 1));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -32,7 +32,7 @@ class Runtime3D(Runtime):
         patches, Do = ops.im2col3d(v.act, D, Cin, kernel, stride, pad)
         K, Kp = Cin * kernel[0] * kernel[1] * kernel[2], patches.C
         w1 = torch.zeros(cs, Kp, 1, 1, dtype=torch.float32, device=self.device)
-        w1[:Cout, :K, 0, 0] = w.detach().reshape(Cout, K)
+        w1[:Cout, :K, 0, 0] = w.detach().permute(0, 2, 3, 4, 1).reshape(Cout, K)     # tap-major, channel-minor columns
         wf, wb = ops.conv_pack(w1, self.dtype, want_bwd=self.need_grad and need_dx)
         y = Var(self.new(patches.N, patches.H, patches.W, cs))
         ops.conv_fwd(patches, wf, cs, y.act, taps=1)
@@ -42,7 +42,7 @@ class Runtime3D(Runtime):
             dw = torch.empty(cs, K, dtype=torch.float32, device=self.device)
             ops.conv_wgrad(patches, dy, dw, taps=1, cin_real=K)
             g = self.alloc_grad(wname, w)
-            g.copy_(dw[:Cout].view_as(w))
+            g.copy_(dw[:Cout].view(Cout, *kernel, Cin).permute(0, 4, 1, 2, 3))
             self._emit(wname, g)
             if need_dx:
                 dpatches = self.new(patches.N, patches.H, patches.W, Kp)

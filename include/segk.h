@@ -187,10 +187,11 @@ int segk_conv3d_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_
                       const void* dy, int64_t ld_dy, int64_t Cout, float* dw, int flags, void* workspace,
                       size_t workspace_bytes, int dev, void* stream);
 
-/* Patch gather for the strided stem convolutions: patches[n,od,oh,ow, ((c*kd+a)*kh+b)*kw+e] =
+/* Patch gather for the strided stem convolutions: patches[n,od,oh,ow, ((a*kh+b)*kw+e)*C+c] =
  * x[n, od*sd-pd+a, oh*sh-ph+b, ow*sw-pw+e, c] for the first C (<= 8) channels of x, zero outside the volume and in
- * columns [C*kd*kh*kw, Kp); kernel/stride/pad are int[3] = (depth, height, width).  The column order equals a
- * flattened Conv3d weight, so the convolution is segk_conv_fwd(taps=1) on the patches.
+ * columns [C*kd*kh*kw, Kp); kernel/stride/pad are int[3] = (depth, height, width).  Columns are tap-major,
+ * channel-minor: with the Conv3d weight permuted to [Cout, kd, kh, kw, C] and flattened, the convolution is
+ * segk_conv_fwd(taps=1) on the patches.
  * replaces: the im2col half of nn.Conv3d(in_classes, 3, (3,7,7), stride (1,2,2), padding (1,3,3)) (models/resnt.py:30)
  *           and nn.Conv3d(3, 64, (7,7,7), stride (1,2,2), padding (3,3,3)) (models/densenet3d.py:98-104).
  * segk_col2im3d is its adjoint (the data gradient w.r.t. x from the patch gradient); flags bit1: accumulate.     */

@@ -98,7 +98,7 @@ def test_stem_conv_patches(dtype, case):
     K = Cin * k[0] * k[1] * k[2]
     cs = (Cout + 7) // 8 * 8
     w1 = torch.zeros(cs, patches.C, 1, 1)
-    w1[:Cout, :K, 0, 0] = w.reshape(Cout, K)
+    w1[:Cout, :K, 0, 0] = w.permute(0, 2, 3, 4, 1).reshape(Cout, K)      # tap-major, channel-minor columns
     wf, wb = ops.conv_pack(w1.cuda(), dtype)
     y = ops.Act.empty(patches.N, patches.H, patches.W, cs, dtype, "cuda")
     ops.conv_fwd(patches, wf, cs, y, taps=1)
