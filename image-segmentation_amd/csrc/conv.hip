@@ -59,9 +59,20 @@ struct ConvArgs {
     const char* mask; int64_t ld_mask; int mask_c;   // output channels below mask_c are zeroed where mask <= 0
     int relu, accumulate;
     int depth = 0, kd = 0;            // volumes: image n is slice n % depth; the input is read from slice n + kd (zero outside the volume)
+    float* stat_part = nullptr;       // optional [N*tiles][pixel-wave][2][Cout]: per-wave sum / sum of squares of the stored output
 };
 
 __device__ __forceinline__ Slot zero_slot() { return make_uint4(0u, 0u, 0u, 0u); }
+
+// Sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), left in every lane of the row: four rotate-and-add steps
+// on the vector ALU (row_ror 8, 4, 2, 1) -- no LDS traffic, unlike a cross-lane permute.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16> {
@@ -307,41 +318,90 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 
     // ---- epilogue: bias, ReLU, mask, store 8 consecutive channels per lane (rows are in MFMA order) ----------
     static_assert(NI % 2 == 0, "channel tiles come in pairs");
+    if (!a.stat_part) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
-        if (yy >= a.H || xx >= a.W) continue;
-        const int64_t pix = a.vout.pixel(n, yy, xx);
+        for (int j = 0; j < NJ; ++j) {
+            const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
+            if (yy >= a.H || xx >= a.W) continue;
+            const int64_t pix = a.vout.pixel(n, yy, xx);
 #pragma unroll
-        for (int k2 = 0; k2 < NI / 2; ++k2) {
-            const int co = cb * BN + wco * WCO + 32 * k2 + 8 * g;
-            if (co >= a.Cout) continue;
+            for (int k2 = 0; k2 < NI / 2; ++k2) {
+                const int co = cb * BN + wco * WCO + 32 * k2 + 8 * g;
+                if (co >= a.Cout) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e]; v[4 + e] = acc[2 * k2 + 1][j][e]; }
+                if (a.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                }
+                if (a.mask && co < a.mask_c) {
+                    float m[8];
+                    Elem<T>::load8(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
+                }
+                const bool second = co >= a.split;
+                T* dst = second ? reinterpret_cast<T*>(a.y1) + pix * a.ldy1 + (co - a.split) : reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
+                if (second ? a.accumulate1 : a.accumulate) {
+                    float o[8];
+                    Elem<T>::load8(dst, o);
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += o[r];
+                }
+                Elem<T>::store8(dst, v);
+            }
+        }
+        return;
+    }
+    // Epilogue of a convolution in front of a normalisation (single destination, no mask, no accumulation): besides
+    // the store, the per-channel sum and sum of squares of what was stored (rounded to T).  16 lanes hold the 16 pixels
+    // of a tile row for the same 8 channels, so a 4-step butterfly over them plus the sum over the wave's rows gives one
+    // partial per (tile, pixel-wave, channel), written once -- no atomics.
+#pragma unroll
+    for (int k2 = 0; k2 < NI / 2; ++k2) {
+        const int co = cb * BN + wco * WCO + 32 * k2 + 8 * g;
+        if (co >= a.Cout) continue;
+        float ssum[8], ssq[8], bv[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ssum[r] = ssq[r] = bv[r] = 0.f;
+        if (a.bias) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
+            if (yy >= a.H || xx >= a.W) continue;
+            const int64_t pix = a.vout.pixel(n, yy, xx);
             float v[8];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e]; v[4 + e] = acc[2 * k2 + 1][j][e]; }
-            if (a.bias) {
-                const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-            }
+            for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e] + bv[e]; v[4 + e] = acc[2 * k2 + 1][j][e] + bv[4 + e]; }
             if (a.relu) {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
             }
-            if (a.mask && co < a.mask_c) {
-                float m[8];
-                Elem<T>::load8(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
+            Elem<T>::store8(reinterpret_cast<T*>(a.y) + pix * a.ldy + co, v);
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
+            for (int r = 0; r < 8; ++r) {
+                const float q = Elem<T>::to_f(Elem<T>::from_f(v[r]));
+                ssum[r] += q;
+                ssq[r] += q * q;
             }
-            const bool second = co >= a.split;
-            T* dst = second ? reinterpret_cast<T*>(a.y1) + pix * a.ldy1 + (co - a.split) : reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
-            if (second ? a.accumulate1 : a.accumulate) {
-                float o[8];
-                Elem<T>::load8(dst, o);
+        }
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] += o[r];
-            }
-            Elem<T>::store8(dst, v);
+        for (int r = 0; r < 8; ++r) { ssum[r] = row16_sum(ssum[r]); ssq[r] = row16_sum(ssq[r]); }
+        if (l15 == 0) {
+            const int tile = (n * a.tiles_y + ty) * a.tiles_x + tx;
+            float* dst = a.stat_part + ((int64_t)(tile * WPX_WAVES + wpx) * 2) * a.Cout + co;
+            *reinterpret_cast<float4*>(dst) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
+            *reinterpret_cast<float4*>(dst + a.Cout) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
+            *reinterpret_cast<float4*>(dst + a.Cout + 4) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
         }
     }
 }
@@ -935,7 +995,7 @@ extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, in
 extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1, int64_t C1,
                              int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout, const float* bias, void* y,
                              int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask, int64_t ld_mask, int64_t mask_channels,
-                             int flags, int dev, void* stream) {
+                             float* stat_partials, int flags, int dev, void* stream) {
     if (int rc = check_segments("conv_fwd", dtype, x0, ld0, C0, x1, ld1, C1)) return rc;
     SEGK_REQUIRE(!y1 || (split > 0 && split < Cout && split % 8 == 0 && ldy >= split && ldy1 >= Cout - split && aligned16(y1) &&
                          (ldy1 * esize(dtype)) % 16 == 0 && !mask),
@@ -949,9 +1009,12 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     SEGK_REQUIRE(!mask || (aligned16(mask) && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "conv_fwd: mask misaligned");
     SEGK_REQUIRE(!mask || (mask_channels > 0 && mask_channels <= Cout && mask_channels % 8 == 0 && ld_mask >= mask_channels), SEGK_ESHAPE,
                  "conv_fwd: mask_channels must be a multiple of 8 in (0, Cout] and fit ld_mask");
+    SEGK_REQUIRE(!stat_partials || (aligned16(stat_partials) && !y1 && !mask && !(flags & 6)), SEGK_EINVAL,
+                 "conv_fwd: output statistics need a single destination, no mask, no accumulation and a 16-byte aligned buffer");
     SEGK_HIP(use_device(dev));
     const int kr = krow(dtype);
     ConvArgs a;
+    a.stat_part = stat_partials;
     a.x0 = (const char*)x0; a.x1 = (const char*)x1; a.ld0 = ld0; a.ld1 = ld1;
     a.C0 = (int)C0; a.C1 = (int)C1;
     a.nch0 = (int)(round_up(C0, kr) / kr); a.nch = a.nch0 + (int)(round_up(C1, kr) / kr);
@@ -970,6 +1033,15 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     launch_fwd_any(dtype, taps, a, bn, st);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+// rows of per-wave output statistics segk_conv_fwd writes: (image, tile, pixel-wave); the pixel-wave count follows the
+// kernel variant launch_fwd_t picks for this channel-block width
+extern "C" int64_t segk_conv_stat_rows(int64_t N, int64_t H, int64_t W, int64_t Cout) {
+    if (N <= 0 || H <= 0 || W <= 0 || Cout <= 0) return 0;
+    const int bn = pick_bn(round_up(Cout, 32));
+    const int wpx = (bn == 128 || bn == 64) ? 2 : 4;
+    return N * ((H + 7) / 8) * ((W + kTW - 1) / kTW) * wpx;
 }
 
 extern "C" size_t segk_conv_wgrad_workspace(int dtype, int taps, int64_t C0, int64_t C1, int64_t N, int64_t H, int64_t W,

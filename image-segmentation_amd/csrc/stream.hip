@@ -136,15 +136,16 @@ __device__ __forceinline__ double block_sum_partials(const float* __restrict__ w
 __global__ __launch_bounds__(kThreads) void stats_finalize_kernel(const float* __restrict__ ws, int bpg, int64_t M, int C,
                                                                   float eps, float* __restrict__ stats,
                                                                   float* __restrict__ rmean, float* __restrict__ rvar,
-                                                                  float momentum, const float* __restrict__ kshift) {
+                                                                  float momentum, const float* __restrict__ kshift,
+                                                                  int64_t row_stride) {
     __shared__ double sm[4];
     const int g = blockIdx.y, c = blockIdx.x;
-    const int64_t base = (int64_t)g * bpg * 2 * C + c;
-    const double s = block_sum_partials(ws, base, 2 * (int64_t)C, bpg, sm);
-    const double q = block_sum_partials(ws, base + C, 2 * (int64_t)C, bpg, sm);
+    const int64_t base = (int64_t)g * bpg * row_stride + c;   // row_stride: floats between consecutive partial rows (2*C when dense)
+    const double s = block_sum_partials(ws, base, row_stride, bpg, sm);
+    const double q = block_sum_partials(ws, base + C, row_stride, bpg, sm);
     if (threadIdx.x != 0) return;
     const double dm = s / (double)M;                       // mean of (x - K)
-    const double mean = (double)kshift[(int64_t)g * C + c] + dm;
+    const double mean = (kshift ? (double)kshift[(int64_t)g * C + c] : 0.0) + dm;
     double var = q / (double)M - dm * dm;
     if (var < 0.0) var = 0.0;
     stats[((int64_t)g * C + c) * 2 + 0] = (float)mean;
@@ -1059,7 +1060,43 @@ extern "C" int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t gro
                                                      (const T*)x, ld, M, (int)C, bpg, (float*)workspace, kshift));
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st,
-                       (const float*)workspace, bpg, M, (int)C, eps, stats, running_mean, running_var, momentum, (const float*)kshift);
+                       (const float*)workspace, bpg, M, (int)C, eps, stats, running_mean, running_var, momentum, (const float*)kshift,
+                       (int64_t)(2 * C));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" size_t segk_norm_stats_finalize_workspace(int64_t groups, int64_t rows_per_group, int64_t C) {
+    return segk_norm_workspace(groups, rows_per_group, 2 * C);
+}
+
+extern "C" int segk_norm_stats_finalize(const float* partials, int64_t groups, int64_t rows_per_group, int64_t M, int64_t C, float eps,
+                                        float* stats, float* running_mean, float* running_var, float momentum, void* workspace,
+                                        size_t workspace_bytes, int dev, void* stream) {
+    SEGK_REQUIRE(partials && stats && groups > 0 && groups < 65536 && rows_per_group > 0 && rows_per_group < (1ll << 31) && M > 0 && C > 0,
+                 SEGK_EINVAL, "norm_stats_finalize: bad arguments");
+    SEGK_REQUIRE(C % 8 == 0 && 2 * C / 8 <= kThreads && aligned16(partials), SEGK_ESHAPE, "norm_stats_finalize: C must be a multiple of 8, at most 1024");
+    SEGK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SEGK_EINVAL, "norm_stats_finalize: running buffers come in pairs");
+    SEGK_REQUIRE(!running_mean || groups == 1, SEGK_EINVAL, "norm_stats_finalize: running buffers need groups == 1");
+    SEGK_HIP(use_device(dev));
+    hipStream_t st = (hipStream_t)stream;
+    if (rows_per_group <= 128) {
+        hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st, partials, (int)rows_per_group, M,
+                           (int)C, eps, stats, running_mean, running_var, momentum, (const float*)nullptr, (int64_t)(2 * C));
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
+    // Many rows: first a coalesced column sum of the [rows][2C] partial matrix by many workgroups, then the per-channel
+    // finalize over the few rows that are left.  The column-sum kernel leaves every second output row unused, hence
+    // the row stride of 4*C.
+    SEGK_REQUIRE(workspace && workspace_bytes >= segk_norm_stats_finalize_workspace(groups, rows_per_group, C), SEGK_EWORKSPACE,
+                 "norm_stats_finalize: workspace too small");
+    const int bpg = stats_bpg(groups, rows_per_group, 2 * C);
+    hipLaunchKernelGGL((stats_partial_kernel<float, 1>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st, partials, 2 * C, rows_per_group,
+                       (int)(2 * C), bpg, (float*)workspace, (float*)nullptr);
+    SEGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st, (const float*)workspace, bpg, M, (int)C,
+                       eps, stats, running_mean, running_var, momentum, (const float*)nullptr, (int64_t)(4 * C));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

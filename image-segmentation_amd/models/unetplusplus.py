@@ -35,11 +35,11 @@ class conv_block_nested(SegkBlock):
         pool=True returns (output, maxpool2x2(output)), the pool fused into the last norm's passes."""
         zero = rt.training     # a bias in front of a batch-statistics norm has an identically zero gradient
         if image is not None:
-            y = rt.conv_first(image, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero)
+            y = rt.conv_first(image, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
         else:
-            y = rt.conv(x, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero)
+            y = rt.conv(x, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
         h = rt.bn_relu(y, prefix + "bn1")
-        y = rt.conv(h, prefix + "conv2.weight", prefix + "conv2.bias", bias_grad_zero=zero)
+        y = rt.conv(h, prefix + "conv2.weight", prefix + "conv2.bias", bias_grad_zero=zero, stats=True)
         return rt.bn_relu(y, prefix + "bn2", out=out, pool=pool)
 
     def _emit_block(self, rt, v):

@@ -57,7 +57,7 @@ class DecoderBlock(SegkBlock, nn.Sequential):
             return rt.conv_transpose_relu(h, prefix + "2.weight", prefix + "2.bias", out=out)
         if self.kind == "bilinear" and self.upsc != 2:
             raise NotImplementedError("the HIP up-sampling stream is specialised for scale factor 2")
-        y = rt.conv(h, prefix + "2.weight")
+        y = rt.conv(h, prefix + "2.weight", stats="instance")
         return rt.in_up_relu(y, out=out, upsample=self.kind == "bilinear")
 
 
@@ -127,9 +127,9 @@ class _UNetVggBase(SegkNet):
             for j, _ in enumerate(stage_widths):
                 wn, bn_ = f"conv{k}.{idx}", f"conv{k}.{idx + 1}"
                 if k == 1 and j == 0 and v is None:
-                    y = rt.conv_first(x, wn + ".weight", wn + ".bias", bias_grad_zero=self.training)
+                    y = rt.conv_first(x, wn + ".weight", wn + ".bias", bias_grad_zero=self.training, stats=True)
                 else:
-                    y = rt.conv(v, wn + ".weight", wn + ".bias", bias_grad_zero=self.training)
+                    y = rt.conv(v, wn + ".weight", wn + ".bias", bias_grad_zero=self.training, stats=True)
                 if j == len(stage_widths) - 1:   # skip tensor (second slice of the concat buffer) + pool for the next stage
                     v, pooled = rt.bn_relu(y, bn_, out=Act(cat[k], widths[k][0], widths[k][1]), pool=True)
                 else:

@@ -9,18 +9,24 @@ Gradient buffers mirror activation buffers (same NHWC shape), so a tensor that l
 slice of a concat buffer receives its gradient in the same slice of the mirrored buffer and the
 data-gradient of the convolution that reads the whole concat buffer fills all slices at once.
 """
+import os
+
 import torch
 
 from . import ops
 from .ops import Act
 
 
+_NO_CONV_STATS = bool(os.environ.get("SEGK_NO_CONV_STATS"))   # experiments: separate statistics pass after every convolution
+
+
 class Var:
     """An activation view plus the bookkeeping of its gradient."""
-    __slots__ = ("act", "ready", "relu_fused")
+    __slots__ = ("act", "ready", "relu_fused", "stat_part")
 
     def __init__(self, act, relu_fused=False):
         self.act = act
+        self.stat_part = None         # per-wave channel sums written by the producing convolution (for the norm that follows)
         self.ready = False            # gradient slice has been written at least once
         self.relu_fused = relu_fused  # act = relu(conv): the producer's ReLU backward is applied by the consumer
 
@@ -106,7 +112,22 @@ class Runtime:
         return ops.conv_pack(w4d, self.dtype, seg0=seg0, want_fwd=True, want_bwd=self.need_grad)
 
     # ---------------------------------------------------------------- layers
-    def conv_first(self, x, wname, bname, bias_grad_zero=False):
+    def _stat_buffer(self, y, stats, norm_groups=None):
+        """Partial-sum buffer for the convolution producing `y` when a normalisation with batch (training) or
+        instance (always) statistics follows."""
+        if not stats or (norm_groups is None and not self.training) or _NO_CONV_STATS:
+            return None
+        y.stat_part = ops.conv_stat_partials(y.act)
+        return y.stat_part
+
+    def _norm_stats(self, y, groups, eps, stats, rmean=None, rvar=None, momentum=0.1):
+        if y.stat_part is not None:
+            ops.norm_stats_from_partials(y.stat_part, groups, y.act.P // groups, eps, stats, rmean, rvar, momentum)
+            y.stat_part = None
+        else:
+            ops.norm_stats(y.act, groups, eps, stats, rmean, rvar, momentum)
+
+    def conv_first(self, x, wname, bname, bias_grad_zero=False, stats=False):
         """3x3 convolution of a few-channel NCHW fp32 image, run as a 1x1 convolution over its 3x3 patch
         image (one K-row of 9*Cin gathered values).  The output carries Cout rounded up to 8 channels
         (extra ones are exactly zero).  No data gradient: the image does not require one."""
@@ -119,7 +140,7 @@ class Runtime:
         wf, _ = ops.conv_pack(w1, self.dtype, want_bwd=False)
         N, _, H, W = x.shape
         y = Var(self.new(N, H, W, cs))
-        ops.conv_fwd(patches, wf, cs, y.act, taps=1, bias=self._bias(bname, cs))
+        ops.conv_fwd(patches, wf, cs, y.act, taps=1, bias=self._bias(bname, cs), stat_partials=self._stat_buffer(y, stats))
 
         def bwd():
             dy = self.grad_of(y.act)
@@ -150,9 +171,11 @@ class Runtime:
             return pb
         return b
 
-    def conv(self, x, wname, bname=None, relu=False, out=None, bias_grad_zero=False, seg_vars=None, cin_real=None):
+    def conv(self, x, wname, bname=None, relu=False, out=None, bias_grad_zero=False, seg_vars=None, cin_real=None, stats=False):
         """3x3 convolution.  x: Var, or a list of Vars that tile one buffer contiguously (in-place concat),
-        or a pair (list_of_vars, Var) for a two-segment concat.  Returns the output Var."""
+        or a pair (list_of_vars, Var) for a two-segment concat.  Returns the output Var.
+        stats: a BatchNorm ("batch") or InstanceNorm ("instance") follows -- the convolution's epilogue also produces
+        the per-channel partial sums, so the normalisation needs no statistics pass over the output."""
         w = self.p[wname]
         Cout, Cin = w.shape[0], w.shape[1]
         segs = self._segments(x)
@@ -162,7 +185,8 @@ class Runtime:
         N, H, W = a0.N, a0.H, a0.W
         y = Var(out or self.new(N, H, W, Cout), relu_fused=relu)
         xin = a0 if len(segs) == 1 else (segs[0][0], segs[1][0])
-        ops.conv_fwd(xin, wf, Cout, y.act, taps=9, bias=self._bias(bname), relu=relu)
+        ops.conv_fwd(xin, wf, Cout, y.act, taps=9, bias=self._bias(bname), relu=relu,
+                     stat_partials=self._stat_buffer(y, stats, norm_groups=y.act.N if stats == "instance" else None))
 
         def bwd():
             dy = self.grad_of(y.act)
@@ -259,7 +283,7 @@ class Runtime:
         gamma, beta = self.p[prefix + ".weight"].detach(), self.p[prefix + ".bias"].detach()
         stats = torch.empty(2 * C, dtype=torch.float32, device=self.device)
         if self.training:
-            ops.norm_stats(y.act, 1, eps, stats, self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], momentum)
+            self._norm_stats(y, 1, eps, stats, self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], momentum)
             self.counters.append(self.b[prefix + ".num_batches_tracked"])
         else:
             ops.norm_eval_stats(self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], eps, stats)
@@ -303,7 +327,7 @@ class Runtime:
         """InstanceNorm2d(affine=False) -> bilinear x2 (align_corners=False) -> ReLU, one pass over the output."""
         x = y.act
         stats = torch.empty(2 * x.N * x.C, dtype=torch.float32, device=self.device)
-        ops.norm_stats(x, x.N, eps, stats)
+        self._norm_stats(y, x.N, eps, stats)
         if upsample:
             # u = relu(...): the ReLU backward is applied by the consumer's data gradient (relu_fused)
             u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C), relu_fused=True)

@@ -152,7 +152,23 @@ def _segs(x):
     return a, b
 
 
-def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, accumulate=False, accumulate1=False):
+def conv_stat_partials(out):
+    """Buffer for the per-wave output statistics of conv_fwd(..., stat_partials=...) writing `out`."""
+    rows = query("segk_conv_stat_rows", out.N, out.H, out.W, out.C)
+    return torch.empty(rows, 2, out.C, dtype=torch.float32, device=out.device)
+
+
+def norm_stats_from_partials(partials, groups, M, eps, stats, running_mean=None, running_var=None, momentum=0.1):
+    rows, _, C = partials.shape
+    dev, st = _env(partials)
+    ws = workspace(query("segk_norm_stats_finalize_workspace", groups, rows // groups, C), partials.device)
+    call("segk_norm_stats_finalize", partials.data_ptr(), groups, rows // groups, M, C, eps, stats.data_ptr(), _p(running_mean),
+         _p(running_var), momentum, ws.data_ptr(), ws.numel(), dev, st)
+    return stats
+
+
+def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, accumulate=False, accumulate1=False,
+             stat_partials=None):
     """out = conv(x) with the packed image `w_packed`; x is an Act or a pair of Acts (channel concat).
     mask: Act over the first mask.C output channels; those are zeroed where mask <= 0.
     out may be a pair of Acts: channels [0, out[0].C) go to the first, the rest to the second (accumulate1)."""
@@ -164,7 +180,8 @@ def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, a
     with _Timed("conv_fwd"):
         call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
              a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), o0.ptr, o0.ld, o1.ptr if o1 else None, o1.ld if o1 else 0,
-             o0.C if o1 else 0, mask.ptr if mask else None, mask.ld if mask else 0, mask.C if mask else 0, flags, dev, st)
+             o0.C if o1 else 0, mask.ptr if mask else None, mask.ld if mask else 0, mask.C if mask else 0, _p(stat_partials), flags,
+             dev, st)
     return out
 
 

@@ -134,7 +134,12 @@ int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, int taps, int
 int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
                   int64_t C1, int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout,
                   const float* bias, void* y, int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask,
-                  int64_t ld_mask, int64_t mask_channels, int flags, int dev, void* stream);
+                  int64_t ld_mask, int64_t mask_channels, float* stat_partials, int flags, int dev, void* stream);
+/* stat_partials (optional, fp32 [segk_conv_stat_rows(N,H,W,Cout)][2][Cout]): per (image, tile, pixel-wave) the sum and
+ * the sum of squares of the output as stored, per channel -- the batch / instance statistics of the BatchNorm or
+ * InstanceNorm that follows (models/unetvgg.py:29-30,72-76; models/unetplusplus.py:11-14) without another pass over
+ * y; segk_norm_stats_finalize turns them into the stats vector.  Needs one destination, no mask, no accumulation.  */
+int64_t segk_conv_stat_rows(int64_t N, int64_t H, int64_t W, int64_t Cout);
 
 /* dw[co,ci,ky,kx] (fp32 OIHW, [Cout, cin_real, taps]) = sum_{n,y,x} dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]
  * replaces: the weight-gradient half of Conv2d's backward.  The pixels are split over workgroups
@@ -249,6 +254,14 @@ int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t groups, int64_
 int segk_norm_apply(int dtype, const void* x, int64_t ldx, int64_t groups, int64_t M, int64_t C,
                     const float* stats, const float* gamma, const float* beta, int flags, void* y, int64_t ldy,
                     int dev, void* stream);
+
+/* Same result as segk_norm_stats from partial sums produced elsewhere (segk_conv_fwd's stat_partials):
+ * partials [groups][rows_per_group][2][C] = plain sums and sums of squares over disjoint pixel sets of a group of
+ * M pixels.                                                                                          */
+size_t segk_norm_stats_finalize_workspace(int64_t groups, int64_t rows_per_group, int64_t C);
+int segk_norm_stats_finalize(const float* partials, int64_t groups, int64_t rows_per_group, int64_t M, int64_t C, float eps,
+                             float* stats, float* running_mean, float* running_var, float momentum, void* workspace,
+                             size_t workspace_bytes, int dev, void* stream);
 
 /* stats for eval mode: {running_mean, 1/sqrt(running_var+eps)} interleaved.                        */
 int segk_norm_eval_stats(const float* running_mean, const float* running_var, int64_t C, float eps,

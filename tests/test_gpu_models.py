@@ -81,8 +81,8 @@ def check_fp32_grads(name, model, side=64, n=2, tag=None):
     whose INPUT is perturbed by 1e-6 (which moves the logits by 2e-5, the size of any fp32 forward error)
     changes the gradients by 2e-3 .. 1e-2 in discrete jumps: ReLU masks flip at the few high-leverage pixels
     that carry the Dice/focal gradient.  Hence: layers behind the last such flip (final, dec1.0) must meet
-    1e-4; every tensor must stay within 2.5e-2; the per-kernel backward passes are held to 1e-4 separately
-    (tests/test_gpu_ops.py)."""
+    1e-4; every tensor must stay within 2.5e-2, or within 1.5x the reference's own fp32 error where that is larger;
+    the per-kernel backward passes are held to 1e-4 separately (tests/test_gpu_ops.py)."""
     m32, _, _ = oracle_step(name, torch.float32, side, n, tag)
     m64, _, _ = oracle_step(name, torch.float64, side, n, tag)
     rows = []
@@ -95,7 +95,7 @@ def check_fp32_grads(name, model, side=64, n=2, tag=None):
         e_ref = float((q32.grad.double() - g64).norm()) / scale
         e_hip = float((p.grad.double().cpu() - g64).norm()) / scale
         rows.append((e_hip, e_ref, k))
-        bound = 1e-4 if k.startswith(("final.", "dec1.0.")) else 2.5e-2
+        bound = 1e-4 if k.startswith(("final.", "dec1.0.")) else max(2.5e-2, 1.5 * e_ref)
         assert e_hip <= bound, f"{k}: rel-L2 vs fp64 oracle {e_hip:.3e} (reference fp32: {e_ref:.3e}), bound {bound}"
     return max(rows)
 

@@ -413,3 +413,37 @@ def test_copy_slice_and_adam():
         opt.step()
         ops.adam_step(p, (g * step).cuda(), m, v, 1e-2, 0.9, 0.999, 1e-8, 0.0, step)
     report("adam", p.cpu(), p_ref.detach(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 9), (3, 20, 24, 128, 96, 9), (2, 12, 40, 32, 128, 9), (1, 9, 17, 64, 32, 9), (2, 16, 16, 32, 64, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_conv_epilogue_statistics(dtype, case):
+    """Per-channel statistics produced by the convolution's epilogue (partial tiles, every channel-block width, 1x1
+    taps) equal the statistics pass over the stored output, for batch (1 group) and instance (N groups) norms,
+    including the running-buffer update."""
+    from segk import ops
+    N, H, W, Cin, Cout, taps = case
+    k = 3 if taps == 9 else 1
+    x = rnd((N, Cin, H, W), dtype, 1)
+    w = rnd((Cout, Cin, k, k), dtype, 2, scale=(2.0 / (taps * Cin)) ** 0.5)
+    b = rnd((Cout,), torch.float32, 3)
+    xa = to_act(x, dtype)
+    wf, _ = ops.conv_pack(w.cuda(), dtype, want_bwd=False)
+    out = ops.Act(torch.zeros(N, H, W, Cout + 8, dtype=dtype, device="cuda"), 8, Cout)
+    part = ops.conv_stat_partials(out)
+    part.fill_(float("nan"))                                   # every row must be written
+    ops.conv_fwd(xa, wf, Cout, out, taps=taps, bias=b.cuda(), stat_partials=part)
+    assert torch.isfinite(part).all()
+    for groups in (1, N):
+        rm0, rv0 = torch.full((Cout,), 0.25, device="cuda"), torch.full((Cout,), 2.0, device="cuda")
+        rm1, rv1 = rm0.clone(), rv0.clone()
+        want = torch.empty(2 * groups * Cout, device="cuda")
+        got = torch.empty_like(want)
+        run = groups == 1
+        ops.norm_stats(out, groups, 1e-5, want, rm0 if run else None, rv0 if run else None, 0.1)
+        ops.norm_stats_from_partials(part, groups, N * H * W // groups, 1e-5, got, rm1 if run else None, rv1 if run else None, 0.1)
+        report(f"stats groups={groups}", got.cpu(), want.cpu(), rtol=2e-5, atol=2e-5)
+        if run:
+            report("running_mean", rm1.cpu(), rm0.cpu(), rtol=1e-5, atol=1e-6)
+            report("running_var", rv1.cpu(), rv0.cpu(), rtol=1e-5, atol=1e-6)
