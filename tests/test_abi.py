@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _header_decls():
     src = open(os.path.join(ROOT, "include", "segk.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return re.findall(r"(?:int|size_t|const char\*)\s+(segk_\w+)\s*\(([^)]*)\)\s*;", src)
+    return re.findall(r"(?:int64_t|int|size_t|const char\*)\s+(segk_\w+)\s*\(([^)]*)\)\s*;", src)
 
 
 def test_header_matches_ctypes_prototypes():
