@@ -9,6 +9,7 @@ Gradient buffers mirror activation buffers (same NHWC shape), so a tensor that l
 slice of a concat buffer receives its gradient in the same slice of the mirrored buffer and the
 data-gradient of the convolution that reads the whole concat buffer fills all slices at once.
 """
+import contextlib
 import os
 
 import torch
@@ -18,6 +19,17 @@ from .ops import Act
 
 
 _NO_CONV_STATS = bool(os.environ.get("SEGK_NO_CONV_STATS"))   # experiments: separate statistics pass after every convolution
+# Weight gradients on a second stream: a convolution's weight and data gradients only share their input dy, so the two
+# kernels can run side by side and fill each other's tails and the under-occupied small layers.
+_WGRAD_STREAM = os.environ.get("SEGK_WGRAD_STREAM", "0") == "1"
+_side_streams = {}
+
+
+def side_stream(device, create=True):
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    if key not in _side_streams and create:
+        _side_streams[key] = torch.cuda.Stream(device)
+    return _side_streams.get(key)
 
 
 class Var:
@@ -94,6 +106,29 @@ class Runtime:
         for fn in reversed(self.tape):
             fn()
         self.tape = []
+        self.join_side()
+
+    @contextlib.contextmanager
+    def side(self):
+        """Run the enclosed launches on the side stream, after everything enqueued so far on the current stream."""
+        if not _WGRAD_STREAM or self.device.type != "cuda":
+            yield
+            return
+        s = side_stream(self.device)
+        ev = torch.cuda.Event()
+        ev.record()
+        s.wait_event(ev)
+        with torch.cuda.stream(s):
+            yield
+        self._side_used = True
+
+    def join_side(self):
+        """The current stream waits for the side stream (before gradients are consumed or buffers are released)."""
+        if getattr(self, "_side_used", False):
+            ev = torch.cuda.Event()
+            ev.record(side_stream(self.device))
+            torch.cuda.current_stream().wait_event(ev)
+            self._side_used = False
 
     def release(self):
         self._gradbufs = {}
@@ -191,17 +226,18 @@ class Runtime:
         def bwd():
             dy = self.grad_of(y.act)
             dw = self.alloc_grad(wname, w)
-            ops.conv_wgrad(xin, dy, dw, taps=9, cin_real=Cin)
-            self._emit(wname, dw)
-            if bname is not None:
-                db = self.alloc_grad(bname, self.p[bname])
-                if bias_grad_zero:
-                    self._zero_grad(bname, db)
-                else:
-                    if self.zero_state is not None:
-                        self.zero_state.discard(bname)
-                    ops.colsum(dy, db)
-                self._emit(bname, db)
+            db = self.alloc_grad(bname, self.p[bname]) if bname is not None else None
+            with self.side():
+                ops.conv_wgrad(xin, dy, dw, taps=9, cin_real=Cin)
+                self._emit(wname, dw)
+                if bname is not None:
+                    if bias_grad_zero:
+                        self._zero_grad(bname, db)
+                    else:
+                        if self.zero_state is not None:
+                            self.zero_state.discard(bname)
+                        ops.colsum(dy, db)
+                    self._emit(bname, db)
             self._dgrad(segs, dy, wb, Cin)
         self.record(bwd)
         return y

@@ -61,10 +61,19 @@ class GradBuckets:
         lo, hi = self.ranges[b]
         view = flat_grad[lo:hi]
         if self.comm_stream is not None:
+            from .engine import side_stream
             ready = torch.cuda.Event()
-            ready.record()                                    # on the compute stream, after the last gradient kernel
+            ready.record()                                    # on the current stream, after the last gradient kernel
+            other = side_stream(flat_grad.device, create=False)   # gradients are produced on two streams: wait for both
+            pending = [ready]
+            for st in (other, torch.cuda.default_stream(flat_grad.device)) if other is not None else ():
+                if st != torch.cuda.current_stream(flat_grad.device):
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    pending.append(ev)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ready)
+                for ev in pending:
+                    self.comm_stream.wait_event(ev)
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
                 view.mul_(1.0 / self.world)
                 done = torch.cuda.Event()

@@ -93,9 +93,9 @@ class _Timed:
 
 
 def workspace(nbytes, device):
-    """Per-device scratch buffer; every kernel that uses it runs on the current stream, so successive
-    uses are ordered."""
-    key = (device.type, device.index)
+    """Scratch buffer per (device, stream): every kernel that uses it runs on that stream, so successive uses are
+    ordered."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -271,3 +271,16 @@ def test_standalone_blocks(kind, kw, shape):
     # the CPU path of the same module is plain torch.nn
     yc = blk.cpu()(x)
     report(f"{kind}/host_out", yc.detach(), yr.detach().float(), rtol=1e-4, atol=1e-5)
+
+
+def test_weight_gradients_on_side_stream(monkeypatch):
+    """Opt-in SEGK_WGRAD_STREAM=1: weight-gradient kernels run on a second stream next to the data gradients.  Same
+    kernels, same order per tensor, so every gradient is bitwise identical to the single-stream run."""
+    from segk import engine
+    grads = []
+    for flag in (False, True):
+        monkeypatch.setattr(engine, "_WGRAD_STREAM", flag)
+        model, logits, loss = run_step("unetvgg_c4", torch.bfloat16)
+        grads.append([p.grad.clone() for p in model.parameters()] + [logits, loss])
+    for a, b in zip(*grads):
+        assert torch.equal(a, b)
