@@ -410,9 +410,8 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 // weight packing: fp32 OIHW -> swizzled K-row images
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
-                                                                 int seg0, char* __restrict__ wf, char* __restrict__ wb,
-                                                                 int64_t w_so, int64_t w_si) {
+__device__ __forceinline__ void conv_pack_body(const float* __restrict__ w, int Cout, int Cin, int taps, int seg0, char* __restrict__ wf,
+                                               char* __restrict__ wb, int64_t w_so, int64_t w_si, int64_t first, int64_t step) {
     constexpr int EPS = 16 / (int)sizeof(T);
     constexpr int KR = KRow<T>::kElems;
     // forward image: rows = Cout rounded up to 32 per (chunk,tap); K = input channels, each input
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __
     const int kb_pad = (Cout + KR - 1) / KR * KR;
     const int rows_b = (Cin + 31) / 32 * 32;
     const int64_t nb = wb ? (int64_t)(kb_pad / KR) * taps * rows_b * 8 : 0;
-    for (int64_t i = (int64_t)blockIdx.x * kConvThreads + threadIdx.x; i < nf + nb; i += (int64_t)gridDim.x * kConvThreads) {
+    for (int64_t i = first; i < nf + nb; i += step) {
         const bool fwd = i < nf;
         int64_t r = fwd ? i : i - nf;
         const int sl = (int)(r & 7); r >>= 3;
@@ -456,6 +455,22 @@ __global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kConvThreads) void conv_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int taps,
+                                                                 int seg0, char* __restrict__ wf, char* __restrict__ wb,
+                                                                 int64_t w_so, int64_t w_si) {
+    conv_pack_body<T>(w, Cout, Cin, taps, seg0, wf, wb, w_so, w_si, (int64_t)blockIdx.x * kConvThreads + threadIdx.x,
+                      (int64_t)gridDim.x * kConvThreads);
+}
+
+// Many weight tensors in one launch: blockIdx.y selects the descriptor, the workgroups of a row share its slots.
+template <typename T>
+__global__ __launch_bounds__(kConvThreads) void conv_pack_batch_kernel(const segk_pack_desc* __restrict__ descs) {
+    const segk_pack_desc d = descs[blockIdx.y];
+    conv_pack_body<T>(d.w, d.Cout, d.Cin, d.taps, d.seg0, (char*)d.wf, (char*)d.wb, d.w_so, d.w_si,
+                      (int64_t)blockIdx.x * kConvThreads + threadIdx.x, (int64_t)gridDim.x * kConvThreads);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -988,6 +1003,16 @@ extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, in
     if (grid > 4096) grid = 4096;
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3((unsigned)grid), dim3(kConvThreads), 0, (hipStream_t)stream,
                                                      w_oihw, (int)Cout, (int)Cin, taps, (int)seg0, (char*)wf, (char*)wb, Cin * taps, (int64_t)taps));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_conv_pack_batch(int dtype, const segk_pack_desc* descs_dev, int64_t n, int64_t blocks_per_desc, int dev, void* stream) {
+    SEGK_REQUIRE(descs_dev && n > 0 && n < 65536 && blocks_per_desc > 0 && blocks_per_desc <= 1024, SEGK_EINVAL, "conv_pack_batch: bad arguments");
+    SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "conv_pack_batch: unknown dtype");
+    SEGK_HIP(use_device(dev));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_batch_kernel<T>), dim3((unsigned)blocks_per_desc, (unsigned)n), dim3(kConvThreads), 0,
+                                                     (hipStream_t)stream, descs_dev));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -29,6 +29,7 @@ _PROTOS = {
     "segk_conv_krow": (I, [I]),
     "segk_conv_packed_bytes": (Z, [I, L, L, I, L]),
     "segk_conv_pack": (I, [P, L, L, I, L, I, P, P, I, P]),
+    "segk_conv_pack_batch": (I, [I, P, L, L, I, P]),
     "segk_conv_fwd": (I, [I, I, P, L, L, P, L, L, L, L, L, P, L, P, P, L, P, L, L, P, L, L, P, I, I, P]),
     "segk_conv_stat_rows": (L, [L, L, L, L]),
     "segk_norm_stats_finalize_workspace": (Z, [L, L, L]),

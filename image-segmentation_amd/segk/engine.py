@@ -58,6 +58,7 @@ class Runtime:
         # tensors outlive the step): an analytically-zero gradient is then not rewritten every step
         self.zero_state = zero_state if grad_alloc is not None else None
         self.counters = []                      # BatchNorm num_batches_tracked buffers to bump once, together
+        self.pack_plan = None                   # segk.packplan.PackPlan of the network (None: pack layer by layer)
 
     # ---------------------------------------------------------------- buffers
     def new(self, N, H, W, C, zero=False):
@@ -143,8 +144,23 @@ class Runtime:
         return Var(Act.from_nchw(x.detach(), self.dtype))
 
     # ---------------------------------------------------------------- packed weights
-    def _pack(self, w4d, seg0=0):
-        return ops.conv_pack(w4d, self.dtype, seg0=seg0, want_fwd=True, want_bwd=self.need_grad)
+    def _pack(self, wname, seg0=0, view=None):
+        """Packed images of parameter `wname` (view: shape to read it as, e.g. [Cout,Cin,1,1] for a 1x1x1 Conv3d weight).
+        With a replayed PackPlan the images were already written by this forward's single batched launch."""
+        key = (wname, seg0)
+        plan = self.pack_plan
+        if plan is not None and plan.ready and key in plan.entries:
+            return plan.entries[key]
+        w = self.p[wname].detach()
+        if view is not None:
+            w = w.reshape(view)
+        if w.dim() == 5:
+            wf, wb = ops.conv3d_pack(w, self.dtype, want_bwd=self.need_grad)
+        else:
+            wf, wb = ops.conv_pack(w, self.dtype, seg0=seg0, want_fwd=True, want_bwd=self.need_grad)
+        if plan is not None and not plan.ready:
+            plan.record(key, wname, w, self.dtype, wf, wb, seg0=seg0)
+        return wf, wb
 
     # ---------------------------------------------------------------- layers
     def _stat_buffer(self, y, stats, norm_groups=None):
@@ -215,7 +231,7 @@ class Runtime:
         Cout, Cin = w.shape[0], w.shape[1]
         segs = self._segments(x)
         seg0 = segs[0][0].C if len(segs) == 2 else 0
-        wf, wb = self._pack(w.detach(), seg0=seg0)
+        wf, wb = self._pack(wname, seg0=seg0)
         a0 = segs[0][0]
         N, H, W = a0.N, a0.H, a0.W
         y = Var(out or self.new(N, H, W, Cout), relu_fused=relu)

@@ -58,7 +58,7 @@ class Runtime3D(Runtime):
         Cout, Cin = w.shape[0], w.shape[1]
         a = x.act
         assert a.C == Cin
-        wf, wb = ops.conv_pack(w.detach().reshape(Cout, Cin, 1, 1), self.dtype, want_bwd=self.need_grad)
+        wf, wb = self._pack(wname, view=(Cout, Cin, 1, 1))
         y = Var(out or self.new(a.N, a.H, a.W, Cout))
         ops.conv_fwd(a, wf, Cout, y.act, taps=1)
 
@@ -78,7 +78,7 @@ class Runtime3D(Runtime):
         Cout, Cin = w.shape[0], w.shape[1]
         a = x.act
         assert a.C == Cin
-        wf, wb = ops.conv3d_pack(w.detach(), self.dtype, want_bwd=self.need_grad)
+        wf, wb = self._pack(wname)
         y = Var(out or self.new(a.N, a.H, a.W, Cout))
         ops.conv3d_fwd(a, D, wf, y.act)
 

@@ -12,6 +12,7 @@ from torch import nn
 
 from . import _lib, ops
 from .engine import Runtime
+from .packplan import PackPlan
 
 _DEFAULT_DTYPE = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32, "float32": torch.float32}[
     os.environ.get("SEGK_DTYPE", "fp32").lower()]
@@ -35,7 +36,18 @@ class _TapeFn(torch.autograd.Function):
             net._segk_zero_grads = set()
         rt = net._runtime_cls(dict(zip(names, params)), dict(net.named_buffers()), dtype, x.device, net.training, need_grad,
                               grad_sink=hooks[0], grad_alloc=hooks[1], zero_state=net._segk_zero_grads)
+        # weight packing: replay the recorded plan of this configuration in one launch, or record one
+        plans = net.__dict__.setdefault("_segk_pack_plans", {})
+        key = (dtype, need_grad, net.training)
+        plan = plans.get(key)
+        if plan is not None and plan.ready and plan.valid(rt.p):
+            plan.run(x.device)
+        else:
+            plan = plans[key] = PackPlan()
+        rt.pack_plan = plan
         logits = net._emit(rt, x)
+        if not plan.ready:
+            plan.finalize(x.device)
         rt.finish_forward()
         ctx.rt, ctx.names, ctx.hooks = rt, names, hooks
         ctx.set_materialize_grads(False)

@@ -120,6 +120,20 @@ size_t segk_conv_packed_bytes(int dtype, int64_t Cout, int64_t Cin, int taps, in
 int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, int taps, int64_t seg0, int dtype, void* wf,
                    void* wb, int dev, void* stream);
 
+/* The same packing for many weight tensors in ONE launch (a training step repacks every layer after the optimizer
+ * update): `descs_dev` is a DEVICE array of n descriptors; element (co, ci, tap) of tensor i is read at
+ * w[co*w_so + ci*w_si + tap] (contiguous OIHW: w_so = Cin*taps, w_si = taps; depth tap kd of a [Cout,Cin,3,3,3]
+ * Conv3d weight: w + kd*9, w_so = Cin*27, w_si = 27).  seg0 = Cin for a single-segment input.  wf / wb may be NULL.
+ * blocks_per_desc workgroups share the slots of one descriptor.                                              */
+typedef struct segk_pack_desc {
+    const float* w;
+    void* wf;
+    void* wb;
+    int32_t Cout, Cin, taps, seg0;
+    int64_t w_so, w_si;
+} segk_pack_desc;
+int segk_conv_pack_batch(int dtype, const segk_pack_desc* descs_dev, int64_t n, int64_t blocks_per_desc, int dev, void* stream);
+
 /* y[n,y,x,co] = act( bias[co] + sum_{tap,ci} x[n,y+ky-1,x+kx-1,ci] * w[co,ci,ky,kx] ) * (mask>0)
  * replaces: nn.Conv2d(k=3,padding=1) forward (models/unetvgg.py:28,34,38,72-76,87;
  *           models/unetplusplus.py:11,13) and -- called with the `wb` image on dy -- the
