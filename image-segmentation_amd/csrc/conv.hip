@@ -426,12 +426,14 @@ __device__ __forceinline__ void conv_pack_body(const float* __restrict__ w, int 
     const int64_t nb = wb ? (int64_t)(kb_pad / KR) * taps * rows_b * 8 : 0;
     for (int64_t i = first; i < nf + nb; i += step) {
         const bool fwd = i < nf;
+        // tap fastest: the taps of a (co, ci) pair are contiguous in the fp32 weight, so neighbouring threads read
+        // neighbouring floats and a wavefront's eight loads cover one contiguous stretch of the tensor
         int64_t r = fwd ? i : i - nf;
+        const int tap = (int)(r % taps); r /= taps;
         const int sl = (int)(r & 7); r >>= 3;
         const int rows = fwd ? cout_pad : rows_b;
-        const int row = (int)(r % rows); r /= rows;
-        const int tap = (int)(r % taps);
-        const int chunk = (int)(r / taps);
+        const int row = (int)(r % rows);
+        const int chunk = (int)(r / rows);
         float v[EPS];
 #pragma unroll
         for (int j = 0; j < EPS; ++j) {

@@ -193,7 +193,25 @@ __global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restric
     }
     const T* xb = x + (int64_t)g * M * ldx + v * 8;
     T* yb = y + (int64_t)g * M * ldy + v * 8;
-    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M && r < rows; p += (int64_t)gridDim.x * rows) {
+    if (r >= rows) return;
+    // four rows per trip, all loads issued before the first use: more bytes in flight per wave
+    const int64_t step = (int64_t)gridDim.x * rows;
+    int64_t p = (int64_t)blockIdx.x * rows + r;
+    for (; p + 3 * step < M; p += 4 * step) {
+        float a[4][8];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) Elem<T>::load8(xb + (p + u * step) * ldx, a[u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a[u][j] = a[u][j] * sc[j] + sh[j];
+                if (relu) a[u][j] = fmaxf(a[u][j], 0.f);
+            }
+            Elem<T>::store8(yb + (p + u * step) * ldy, a[u]);
+        }
+    }
+    for (; p < M; p += step) {
         float a[8];
         Elem<T>::load8(xb + p * ldx, a);
 #pragma unroll

@@ -8,7 +8,8 @@ import os
 from ctypes import c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libsegk.so")
+# SEGK_LIB_PATH: another build of the same library (kernel experiments: A/B two builds in one session)
+LIB_PATH = os.environ.get("SEGK_LIB_PATH") or os.path.join(os.path.dirname(_HERE), "libsegk.so")
 
 SEGK_F32, SEGK_BF16 = 0, 1
 _ERR_NAMES = {-1: "SEGK_EINVAL", -2: "SEGK_ESHAPE", -3: "SEGK_EALIGN", -4: "SEGK_EWORKSPACE", -5: "SEGK_EHIP"}

@@ -52,5 +52,6 @@ class PackPlan:
             return
         dev = device.index if device.index is not None else torch.cuda.current_device()
         n = len(self.descs)
-        call("segk_conv_pack_batch", ops.dt(self.dtype), self.table.data_ptr(), n, 64 if n <= 64 else 16, dev,
+        # workgroups per descriptor: enough that the largest tensor (a few 100 K slots) is a handful of trips per thread
+        call("segk_conv_pack_batch", ops.dt(self.dtype), self.table.data_ptr(), n, 256 if n <= 64 else 32, dev,
              torch.cuda.current_stream(dev).cuda_stream)
