@@ -894,8 +894,10 @@ static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
     // (a 16x16-pixel tile on 8 waves, <T, TAPS, 16, 128, 4, 2>, halves the weight traffic into LDS per FLOP but measured
     // 2-5 % slower on the UNet-VGG layers: one 8-wave barrier domain per CU instead of two independent 4-wave ones)
     if constexpr (TAPS == 9 && sizeof(T) == 2) {
-        // thin layers (one or two K-rows of input channels): the high-occupancy variants
-        if (a.nch <= 2 && bn != 128) {
+        // channel blocks narrower than 128: the high-occupancy variants (one halo buffer, 3-4 workgroups per CU) win at
+        // every depth of K (measured up to 5 K-rows: 929 -> 793 us for 320 -> 64 channels at 384^2); a 128-wide block does
+        // not fit three times into a CU's LDS (56 KB each) and gains nothing from the single halo buffer alone
+        if (bn != 128) {
             if (bn == 96) hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 96, 4, 1, 3>), dim3(grid), dim3(kConvThreads), 0, st, a);
             else if (bn == 64) hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 64, 2, 2, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
             else hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 32, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);

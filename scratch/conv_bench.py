@@ -13,6 +13,11 @@ LAYERS = [("conv1.3", 384, 64, 64), ("conv2.7", 192, 64, 128), ("conv2.10", 192,
           ("center.0", 12, 512, 512), ("center.2", 12, 512, 256), ("dec5.0", 24, 768, 512), ("dec5.2", 24, 512, 256),
           ("dec4.0", 48, 768, 512), ("dec4.2", 48, 512, 256), ("dec3.0", 96, 512, 256), ("dec3.2", 96, 256, 64),
           ("dec2.0", 192, 192, 128), ("dec2.2", 192, 128, 32), ("dec1.0", 384, 96, 32)]
+if os.environ.get("SET") == "unetpp":     # UNet++ (batch 16): the full-resolution nested decoder and a few inner nodes
+    N = int(os.environ.get("N", 16))
+    LAYERS = [("x0_1.c1", 384, 128, 64), ("x0_2.c1", 384, 192, 64), ("x0_3.c1", 384, 256, 64), ("x0_4.c1", 384, 320, 64),
+              ("x0_j.c2", 384, 64, 64), ("x1_1.c1", 192, 256, 128), ("x1_3.c1", 192, 512, 128), ("x2_2.c1", 96, 768, 256),
+              ("x3_1.c1", 48, 1024, 512), ("x4_0.c2", 24, 1024, 1024)]
 only = os.environ.get("ONLY")
 if only:
     LAYERS = [l for l in LAYERS if l[0] in only.split(",")]
