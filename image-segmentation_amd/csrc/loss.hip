@@ -60,7 +60,7 @@ template <typename TL, int C, bool VEC>
 __global__ __launch_bounds__(kLossThreads) void dice_focal_fwd_kernel(
     const TL* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ hot,
     int64_t HW, float gamma, const float* __restrict__ alpha, int no_sft, float* __restrict__ focal_map,
-    float* __restrict__ ws, int bpi) {
+    float* __restrict__ ws, int bpi, int sa) {
     const int n = blockIdx.y, b = blockIdx.x;
     const TL* zl = logits + (int64_t)n * C * HW;
     const int64_t* lab = labels ? labels + (int64_t)n * HW : nullptr;
@@ -115,8 +115,9 @@ __global__ __launch_bounds__(kLossThreads) void dice_focal_fwd_kernel(
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     const float gc = (c == t[v]) ? 1.f : 0.f;
-                    accA[c] += px.p[c] * gc;
-                    accB[c] += px.p[c] * px.p[c];
+                    // self-adjusting Dice (loss/dice.py:275-325) weights both sums by 1 - p
+                    accA[c] += sa ? px.p[c] * gc * (1.f - px.p[c]) : px.p[c] * gc;
+                    accB[c] += sa ? px.p[c] * (1.f - px.p[c]) : px.p[c] * px.p[c];
                     accG[c] += gc;
                     // focal weight exactly as the reference forms it: 1 - where(onehot==1, p, 1-p)
                     const float fw = 1.f - ((c == t[v]) ? px.p[c] : (1.f - px.p[c]));
@@ -128,9 +129,9 @@ __global__ __launch_bounds__(kLossThreads) void dice_focal_fwd_kernel(
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
                     fg |= (g[v][c] != 0.f);
-                    accA[c] += px.p[c] * g[v][c];
-                    accB[c] += px.p[c] * px.p[c];
-                    accG[c] += g[v][c] * g[v][c];
+                    accA[c] += sa ? px.p[c] * g[v][c] * (1.f - px.p[c]) : px.p[c] * g[v][c];
+                    accB[c] += sa ? px.p[c] * (1.f - px.p[c]) : px.p[c] * px.p[c];
+                    accG[c] += sa ? g[v][c] : g[v][c] * g[v][c];
                 }
             }
         }
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(kLossThreads) void dice_focal_bwd_kernel(
     const TL* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ hot,
     int64_t HW, float gamma, const float* __restrict__ alpha, int no_sft, int all_chann,
     const float* __restrict__ sums, const int32_t* __restrict__ flags, const float* __restrict__ scalars,
-    const float* __restrict__ gscale, TL* __restrict__ dlogits, int bpi) {
+    const float* __restrict__ gscale, TL* __restrict__ dlogits, int bpi, int sa) {
     const int n = blockIdx.y, b = blockIdx.x;
     const TL* zl = logits + (int64_t)n * C * HW;
     TL* dz = dlogits + (int64_t)n * C * HW;
@@ -258,7 +259,11 @@ __global__ __launch_bounds__(kLossThreads) void dice_focal_bwd_kernel(
             softmax_pixel<C>(z[v], t[v], no_sft != 0, px);
             float u[kMaxC], up = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) { u[c] = gs_d * (k1[c] * g[v][c] + k2[c] * px.p[c]); up += u[c] * px.p[c]; }
+            for (int c = 0; c < C; ++c) {
+                // d(num)/dp = g, d(den)/dp = 2p;  self-adjusting: g (1 - 2p) and (1 - 2p)
+                u[c] = sa ? gs_d * (1.f - 2.f * px.p[c]) * (k1[c] * g[v][c] + 0.5f * k2[c]) : gs_d * (k1[c] * g[v][c] + k2[c] * px.p[c]);
+                up += u[c] * px.p[c];
+            }
             float s_[kMaxC], sp = 0.f, S = 0.f, ce = 0.f, at = 0.f;
             const bool do_focal = lab != nullptr && gs_f != 0.f;
             if (do_focal) {
@@ -367,10 +372,10 @@ static int launch_fwd(const void* logits, const int64_t* labels, const float* ho
     dim3 grid(bpi, (unsigned)N);
     if (vec)
         hipLaunchKernelGGL((dice_focal_fwd_kernel<TL, C, true>), grid, dim3(kLossThreads), 0, st, (const TL*)logits, labels,
-                           hot, HW, gamma, alpha, flags & 1, focal_map, ws, bpi);
+                           hot, HW, gamma, alpha, flags & 1, focal_map, ws, bpi, (flags >> 3) & 1);
     else
         hipLaunchKernelGGL((dice_focal_fwd_kernel<TL, C, false>), grid, dim3(kLossThreads), 0, st, (const TL*)logits, labels,
-                           hot, HW, gamma, alpha, flags & 1, focal_map, ws, bpi);
+                           hot, HW, gamma, alpha, flags & 1, focal_map, ws, bpi, (flags >> 3) & 1);
     return 0;
 }
 
@@ -383,10 +388,10 @@ static int launch_bwd(const void* logits, const int64_t* labels, const float* ho
     dim3 grid(bpi, (unsigned)N);
     if (vec)
         hipLaunchKernelGGL((dice_focal_bwd_kernel<TL, C, true>), grid, dim3(kLossThreads), 0, st, (const TL*)logits, labels,
-                           hot, HW, gamma, alpha, flags & 1, (flags >> 1) & 1, sums, iflags, scalars, gscale, (TL*)dlogits, bpi);
+                           hot, HW, gamma, alpha, flags & 1, (flags >> 1) & 1, sums, iflags, scalars, gscale, (TL*)dlogits, bpi, (flags >> 3) & 1);
     else
         hipLaunchKernelGGL((dice_focal_bwd_kernel<TL, C, false>), grid, dim3(kLossThreads), 0, st, (const TL*)logits, labels,
-                           hot, HW, gamma, alpha, flags & 1, (flags >> 1) & 1, sums, iflags, scalars, gscale, (TL*)dlogits, bpi);
+                           hot, HW, gamma, alpha, flags & 1, (flags >> 1) & 1, sums, iflags, scalars, gscale, (TL*)dlogits, bpi, (flags >> 3) & 1);
     return 0;
 }
 

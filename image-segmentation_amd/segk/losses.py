@@ -7,7 +7,7 @@ from . import _lib
 from .ops import dt, workspace
 from ._lib import call, query
 
-NO_SFT, ALL_CHANN, FOCAL_SUM = 1, 2, 4
+NO_SFT, ALL_CHANN, FOCAL_SUM, SELF_ADJ = 1, 2, 4, 8
 
 
 def _env(t):
@@ -75,15 +75,17 @@ def _as_square_labels(act):
     return act.view(act.shape[0], 1, act.shape[2], act.shape[2])
 
 
-def dice_focal(pred, target, gamma=2.0, alpha=None, no_sft=False, is_all_chann=False, focal_sum=False, want_map=False):
-    flags = (NO_SFT if no_sft else 0) | (ALL_CHANN if is_all_chann else 0) | (FOCAL_SUM if focal_sum else 0)
+def dice_focal(pred, target, gamma=2.0, alpha=None, no_sft=False, is_all_chann=False, focal_sum=False, want_map=False,
+               self_adjusting=False):
+    flags = (NO_SFT if no_sft else 0) | (ALL_CHANN if is_all_chann else 0) | (FOCAL_SUM if focal_sum else 0) | \
+        (SELF_ADJ if self_adjusting else 0)
     return _DiceFocalFn.apply(pred, target, gamma, alpha, flags, want_map)
 
 
 # ------------------------------------------------------------------------------------ public: Dice
-def dice_coefficient_sq(probs, act, ignore_onlybg=False, no_sft=False, is_all_chann=False):
+def dice_coefficient_sq(probs, act, ignore_onlybg=False, no_sft=False, is_all_chann=False, _self_adjusting=False):
     if not probs.is_cuda:
-        return _host_dice_sq(probs, act, no_sft, is_all_chann)
+        return _host_dice_sq(probs, act, no_sft, is_all_chann, _self_adjusting)
     if act.dim() != 4:
         sq = _as_square_labels(act)
         if sq.dtype != torch.int64:
@@ -91,12 +93,28 @@ def dice_coefficient_sq(probs, act, ignore_onlybg=False, no_sft=False, is_all_ch
         target = sq.view(sq.shape[0], sq.shape[2], sq.shape[3])
     else:
         target = act.float()
-    coeff, _ = dice_focal(probs, target, no_sft=no_sft, is_all_chann=is_all_chann)
+    coeff, _ = dice_focal(probs, target, no_sft=no_sft, is_all_chann=is_all_chann, self_adjusting=_self_adjusting)
     return coeff
 
 
 def dice_loss_sq(pred, act, no_sft=False, is_all_chann=False):
     return 1 - dice_coefficient_sq(pred, act, no_sft=no_sft, is_all_chann=is_all_chann)
+
+
+def dice_coefficient_sa(probs, act, ignore_onlybg=False, no_sft=False):
+    """Self-adjusting Dice coefficient (reference loss/dice.py:275-325): (2 sum p g (1-p) + 1) / (sum p (1-p) + sum g + 1),
+    background channel dropped, averaged over the images that contain foreground."""
+    return dice_coefficient_sq(probs, act, no_sft=no_sft, _self_adjusting=True)
+
+
+def dice_loss_sa(pred, act, no_sft=False):
+    """reference loss/dice.py:327-345"""
+    return 1 - dice_coefficient_sa(pred, act, no_sft=no_sft)
+
+
+def logcoshdiceloss(pred, act, no_sft=False):
+    """log(cosh(squared-Dice loss)) (reference loss/dice.py:347-349); the scalar chain rule is autograd's."""
+    return torch.log(torch.cosh(dice_loss_sq(pred, act, no_sft=no_sft)))
 
 
 def dice_coefficient(probs, act, is_list_bat=False, nosft=False, channelcnt=None, is_all_chann=False):
@@ -175,10 +193,14 @@ def _host_fg_mean(table, act, keep_all, need_multi):
     return kept[rows].sum() / denom, kept
 
 
-def _host_dice_sq(scores, act, no_sft, keep_all):
+def _host_dice_sq(scores, act, no_sft, keep_all, self_adjusting=False):
     g = act if act.dim() == 4 else _host_onehot(act, scores.shape[1])
     p = scores if no_sft else scores.softmax(1)
-    table = (2 * (p * g).sum((2, 3)) + 1) / ((p * p).sum((2, 3)) + (g * g).sum((2, 3)) + 1)
+    if self_adjusting:
+        wgt = 1 - p
+        table = (2 * (p * g * wgt).sum((2, 3)) + 1) / ((wgt * p).sum((2, 3)) + g.sum((2, 3)) + 1)
+    else:
+        table = (2 * (p * g).sum((2, 3)) + 1) / ((p * p).sum((2, 3)) + (g * g).sum((2, 3)) + 1)
     return _host_fg_mean(table, act, keep_all, True)[0]
 
 

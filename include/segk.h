@@ -56,7 +56,8 @@ size_t segk_dice_focal_workspace(int64_t N, int64_t C, int64_t HW);
  * out_sums  [N*C*4] fp32: per (n,c) {sum p*g, sum p*p, sum g*g, sum focal_c}            (written)
  * out_flags [N]     int32: 1 if image n has any non-zero target (loss/dice.py:82)        (written)
  * focal_map optional [N,C,H,W] fp32 elementwise focal values (reduction='none')          (written)
- * flags bit0: logits already are probabilities (no_sft, Dice only)                                */
+ * flags bit0: logits already are probabilities (no_sft, Dice only); bit3 (all three calls): self-adjusting Dice
+ * (loss/dice.py:275-325): numerator sum p*g*(1-p), denominator sum p*(1-p) + sum g.                          */
 int segk_dice_focal_fwd(const void* logits, int logits_dtype, const int64_t* labels, const float* hot,
                         int64_t N, int64_t C, int64_t HW, float gamma, const float* alpha, int flags,
                         float* out_sums, int32_t* out_flags, float* focal_map, void* workspace,

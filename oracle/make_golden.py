@@ -105,6 +105,29 @@ def golden_losses(ref, pin):
     np.savez_compressed(os.path.join(GOLD, "losses.npz"), **out)
 
 
+def golden_aux_losses(ref, pin):
+    """Self-adjusting and log-cosh Dice (loss/dice.py:275-349) on the loss cases that use the default Dice options."""
+    dice_ref = ref["loss.dice"]
+    out = {}
+    for name, C, N, side, kw in loss_cases():
+        if side > 64 or any(k in kw for k in ("is_all_chann", "gamma", "alpha", "reduction")):
+            continue
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        nos = bool(kw.get("no_sft"))
+        zin = torch.softmax(z, 1) if nos else z
+        for tag, fn_ref, fn_or in (("sa", dice_ref.dice_loss_sa, RL.dice_loss_sa), ("logcosh", dice_ref.logcoshdiceloss, RL.logcoshdiceloss)):
+            a = zin.clone().requires_grad_(True)
+            la = fn_ref(a, t, no_sft=nos)
+            la.backward()
+            b = zin.clone().requires_grad_(True)
+            lb = fn_or(b, t, no_sft=nos)
+            lb.backward()
+            pin[f"loss/{name}/{tag}"] = bool(bits_equal(la.detach(), lb.detach()) and bits_equal(a.grad, b.grad))
+            out[f"{name}/{tag}"] = la.detach().numpy()
+            out[f"{name}/{tag}_grad"] = a.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "losses_aux.npz"), **out)
+
+
 # ------------------------------------------------------------------------------------ models
 def model_cases(ref):
     uv, up = ref["models.unetvgg"], ref["models.unetplusplus"]
@@ -246,12 +269,17 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
     pin = {}
-    if "--volumes-only" in sys.argv:      # refresh the 3-D fixtures without regenerating the 2-D ones
+    partial = [a for a in ("--volumes-only", "--aux-losses-only") if a in sys.argv]
+    if partial:                           # refresh one fixture file without regenerating the others
         pf = os.path.join(GOLD, "oracle_pin.json")
         pin = json.load(open(pf))["checks"] if os.path.exists(pf) else {}
-        golden_volumes(ref, pin)
+        if "--volumes-only" in partial:
+            golden_volumes(ref, pin)
+        if "--aux-losses-only" in partial:
+            golden_aux_losses(ref, pin)
     else:
         golden_losses(ref, pin)
+        golden_aux_losses(ref, pin)
         golden_models(ref, pin)
         golden_volumes(ref, pin)
     verdict = {"torch": torch.__version__, "numpy": np.__version__, "all_bitwise_equal": all(pin.values()), "checks": pin}

@@ -4,6 +4,7 @@ Pure-torch restatement of the arithmetic of the reference's losses, written from
 reference code evaluates (not from its text):
 
 * soft squared Dice        -- /root/reference/loss/dice.py:25-87  (loss = 1 - coefficient, :22-23)
+* self-adjusting Dice, log-cosh Dice -- /root/reference/loss/dice.py:275-349
 * arg-max Dice metric      -- /root/reference/loss/dice.py:89-184
 * multi-class focal loss   -- /root/reference/loss/focal.py:32-75, 108-137
 
@@ -52,6 +53,28 @@ def dice_coefficient_sq(probs, act, ignore_onlybg=False, no_sft=False, is_all_ch
 
 def dice_loss_sq(pred, act, no_sft=False, is_all_chann=False):
     return 1 - dice_coefficient_sq(pred, act, no_sft=no_sft, is_all_chann=is_all_chann)
+
+
+def dice_coefficient_sa(probs, act, ignore_onlybg=False, no_sft=False):
+    """Self-adjusting Dice (dice.py:275-325): both the overlap and the prediction mass are weighted by 1 - p."""
+    hot = _one_hot(act, probs.shape[1]) if act.dim() != 4 else act
+    p = probs if no_sft else torch.softmax(probs, dim=1)
+    wgt = 1 - p
+    inter = (p * hot * wgt).flatten(2).sum(2)
+    pmass = (wgt * p).flatten(2).sum(2)
+    gmass = hot.clone().flatten(2).sum(2)
+    dice = (2 * inter + 1) / (pmass + gmass + 1)
+    coeff, _ = _average_over_fg(dice, act, False, guard_single_channel=True)
+    return coeff
+
+
+def dice_loss_sa(pred, act, no_sft=False):
+    return 1 - dice_coefficient_sa(pred, act, no_sft=no_sft)
+
+
+def logcoshdiceloss(pred, act, no_sft=False):
+    """dice.py:347-349"""
+    return torch.log(torch.cosh(dice_loss_sq(pred, act, no_sft=no_sft)))
 
 
 def dice_coefficient(probs, act, is_list_bat=False, nosft=False, channelcnt=None, is_all_chann=False):

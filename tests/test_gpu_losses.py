@@ -125,3 +125,28 @@ def test_loss_full_size_properties():
     assert abs(float(lf0) - float(ce)) < 1e-5 * float(ce)
     # determinism: same inputs, same bits
     assert float(dice_loss_sq(z.detach(), t)) == float(ld)
+
+
+def _aux_cases():
+    from oracle.cases import loss_cases
+    return [c for c in loss_cases() if c[3] <= 64 and not any(k in c[4] for k in ("is_all_chann", "gamma", "alpha", "reduction"))]
+
+
+@pytest.mark.parametrize("case", _aux_cases(), ids=lambda c: c[0])
+def test_self_adjusting_and_logcosh_dice_vs_golden(case):
+    """dice_loss_sa / logcoshdiceloss (reference loss/dice.py:275-349) on the fused kernels: values and dlogits against
+    the vectors captured from the reference (tests/golden/losses_aux.npz)."""
+    import os
+    from loss.dice import dice_loss_sa, logcoshdiceloss
+    name, C, N, side, kw = case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses_aux.npz"))
+    z, t = _inputs(name, C, N, side, kw)
+    nos = bool(kw.get("no_sft"))
+    zin = torch.softmax(z, 1) if nos else z
+    for tag, fn in (("sa", dice_loss_sa), ("logcosh", logcoshdiceloss)):
+        a = zin.clone().cuda().requires_grad_(True)
+        loss = fn(a, t.cuda(), no_sft=nos)
+        loss.backward()
+        report(f"{name}/{tag}", loss.detach().cpu(), torch.from_numpy(g[f"{name}/{tag}"]), rtol=1e-5, atol=1e-6)
+        want = torch.from_numpy(g[f"{name}/{tag}_grad"])
+        report(f"{name}/{tag}_grad", a.grad.cpu(), want, rtol=1e-4, atol=1e-4 * float(want.abs().max()) + 1e-12)

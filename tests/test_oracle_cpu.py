@@ -48,6 +48,34 @@ def test_oracle_losses_match_golden(golden):
             report(f"{name}/closed_form", cf.float(), a.grad + b.grad, rtol=1e-4, atol=1e-7)
 
 
+def test_aux_dice_losses_oracle_and_host_path():
+    """Self-adjusting and log-cosh Dice: the oracle reproduces the reference's vectors bit for bit and the product's
+    CPU-tensor path agrees with it."""
+    from oracle import ref_losses as RL
+    from oracle.cases import loss_cases, make_loss_inputs
+    from loss.dice import dice_loss_sa, logcoshdiceloss
+    g = np.load(os.path.join(ROOT, "tests", "golden", "losses_aux.npz"))
+    seen = 0
+    for name, C, N, side, kw in loss_cases():
+        if f"{name}/sa" not in g.files:
+            continue
+        seen += 1
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        nos = bool(kw.get("no_sft"))
+        zin = torch.softmax(z, 1) if nos else z
+        for tag, f_or, f_host in (("sa", RL.dice_loss_sa, dice_loss_sa), ("logcosh", RL.logcoshdiceloss, logcoshdiceloss)):
+            a = zin.clone().requires_grad_(True)
+            la = f_or(a, t, no_sft=nos)
+            la.backward()
+            assert np.array_equal(la.detach().numpy(), g[f"{name}/{tag}"]) and np.array_equal(a.grad.numpy(), g[f"{name}/{tag}_grad"])
+            b = zin.clone().requires_grad_(True)
+            lb = f_host(b, t, no_sft=nos)
+            lb.backward()
+            report(f"{name}/{tag} host", lb, la, rtol=1e-6, atol=1e-7)
+            report(f"{name}/{tag} host grad", b.grad, a.grad, rtol=1e-5, atol=1e-9)
+    assert seen >= 5
+
+
 def test_oracle_known_answers(golden):
     from oracle import ref_losses as RL
     z = torch.zeros(2, 4, 8, 8)
