@@ -85,6 +85,45 @@ def test_train_general_gpu(tmp_path):
     assert float((a - b).norm() / a.norm()) < 1e-3
 
 
+def _export_roundtrip(device, tmp_path):
+    from torch.utils.data import DataLoader
+    from data_read.synthetic import SyntheticSlices
+    from models.unetvgg import UNetVgg
+    from result_utils.save_img import save_pred_one, test_pred
+    from train_helper.naive_train import save_checkpoint
+    torch.manual_seed(3)
+    model = UNetVgg(out_classes=4).to(device)
+    save_checkpoint({"epoch": 1, "arch": "UNetVgg", "state_dict": model.state_dict()}, True, str(tmp_path))
+    loader = DataLoader(SyntheticSlices(4, side=64, n_classes=4), batch_size=2)
+    fresh = UNetVgg(out_classes=4)
+    x, y, pred = test_pred(fresh, str(tmp_path), loader, "t")
+    assert pred.shape == (2, 4, 64, 64) and not fresh.training
+    mask, dice = save_pred_one(x, y, pred, str(tmp_path), fig_name="out1")
+    stored = np.load(os.path.join(tmp_path, "out1_mask.npy"))
+    assert stored.dtype == np.uint8 and np.array_equal(stored, pred.argmax(1).numpy()) and 0.0 <= dice <= 1.0
+    return x, pred
+
+
+def test_mask_export_cpu(tmp_path):
+    _export_roundtrip("cpu", tmp_path)
+
+
+@pytest.mark.gpu
+def test_mask_export_gpu(tmp_path):
+    """test_pred on the GPU: the exported arg-max masks equal those of the same checkpoint evaluated on the CPU path
+    wherever the top-2 logit margin exceeds the fp32 tolerance."""
+    from models.unetvgg import UNetVgg
+    x, pred = _export_roundtrip("cuda", tmp_path)
+    name = [n for n in os.listdir(tmp_path) if "epoch" in n][0]
+    cpu = UNetVgg(out_classes=4)
+    cpu.load_state_dict(torch.load(os.path.join(tmp_path, name), weights_only=True)["state_dict"])
+    with torch.no_grad():
+        ref = cpu.eval()(x)
+    top2 = ref.topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 1e-3
+    assert torch.equal(pred.argmax(1)[safe], ref.argmax(1)[safe]) and float(safe.float().mean()) > 0.9
+
+
 @pytest.mark.gpu
 def test_mid_slice_training_gpu(tmp_path):
     """The call of train_midlslice.py:25-33 (DetectMid, CrossEntropyLoss, naive loop, sgm_train=False) on stand-in
