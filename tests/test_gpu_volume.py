@@ -289,3 +289,32 @@ def test_detectmid_flat_grads_and_adam():
                 assert torch.equal(p.grad, want), k
         opt.step()
     assert torch.isfinite(flat.flat_param).all()
+
+
+def test_detectmid_full_size_properties():
+    """BASELINE volume shape (1 x 64 x 256 x 256, bf16), two volumes: size-independent properties instead of an oracle
+    run -- bitwise run-to-run determinism of outputs and gradients, finite values, a gradient for every parameter of the
+    graph, and (eval mode, running statistics) independence of a volume's scores from the rest of the batch."""
+    from models.resnt import DetectMid
+    from oracle.ref_models import hash_init_, synthetic_volumes
+    model = hash_init_(DetectMid(in_classes=1)).cuda().train().set_compute_dtype(torch.bfloat16)
+    x, t = synthetic_volumes(2, 64, 256, tag="bench:vol")
+    x, t = x.cuda(), t.cuda()
+    outs = []
+    for _ in range(2):
+        model.zero_grad()
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                m.reset_running_stats()
+        out = model(x)
+        F.cross_entropy(out, t).backward()
+        outs.append((out.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.isfinite(outs[0][0]).all()
+    assert len(outs[0][1]) == sum(1 for k, _ in model.named_parameters() if not k.startswith("lastregr"))
+    for k, g in outs[0][1].items():
+        assert torch.isfinite(g).all() and torch.equal(g, outs[1][1][k]), k
+    model.eval()
+    with torch.no_grad():
+        both = model(x)
+        one = model(x[1:2])
+    assert torch.equal(both[1:2], one)
