@@ -58,7 +58,10 @@ struct ConvArgs {
     int xcd_remap = 1;
     const char* mask; int64_t ld_mask; int mask_c;   // output channels below mask_c are zeroed where mask <= 0
     int relu, accumulate;
-    int depth = 0, kd = 0;            // volumes: image n is slice n % depth; the input is read from slice n + kd (zero outside the volume)
+    // volumes (depth > 0): image n is slice n % depth of its volume, and the K dimension runs over the three depth taps:
+    // K-row chunk = kdi * nch0 + c reads channels c of slice n + kdi - 1 (zero beyond the volume's faces)
+    int depth = 0;
+    int64_t slice_bytes = 0;          // bytes between consecutive slices of the input
     float* stat_part = nullptr;       // optional [N*tiles][pixel-wave][2][Cout]: per-wave sum / sum of squares of the stored output
 };
 
@@ -176,9 +179,12 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
     const int ty = sp % a.tiles_y;
     const int n = sp / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * kTW;
-    // depth tap of a volume convolution: the neighbouring slice n + kd, or nothing at the volume's faces
-    const bool slice_ok = a.depth == 0 || (unsigned)(n % a.depth + a.kd) < (unsigned)a.depth;
-    if (!slice_ok && a.accumulate) return;   // block-uniform: y += 0
+    // depth taps of a volume convolution: bit kdi set = slice n + kdi - 1 lies inside the volume
+    int slice_mask = 7;
+    if (a.depth > 0) {
+        const int d = n % a.depth;
+        slice_mask = (d > 0 ? 1 : 0) | 2 | (d + 1 < a.depth ? 4 : 0);
+    }
 
     // ---- staging: global -> LDS by DMA (no registers, stays in flight behind the MFMAs) -------------
     // LDS slot q of the halo image holds pixel q>>3, and -- because the DMA destination is linear in the
@@ -193,21 +199,29 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
         const int pix = q >> 3, sl = (q & 7) ^ (pix & 7);
         const int hy = pix / HW_, hx = pix - hy * HW_;
         const int gy = y0 + hy - PAD, gx = x0 + hx - PAD;
-        const bool in = q < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && slice_ok;
-        hinfo[p] = in ? ((a.vin.pixel(n + a.kd, gy, gx) << 3) | sl) : -1;
+        const bool in = q < HSLOTS && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        hinfo[p] = in ? ((a.vin.pixel(n, gy, gx) << 3) | sl) : -1;
     }
     // transfers of halo part `part` (HL per thread) of K-row `chunk` into halo buffer `buf`
     auto stage_halo_part = [&](int chunk, int buf, int part) {
-        const bool s0 = chunk < a.nch0;
+        bool s0 = chunk < a.nch0, live = true;
         const char* base = s0 ? a.x0 : a.x1;
+        int c = s0 ? chunk : chunk - a.nch0;
+        if (a.depth > 0) {                      // block-uniform: depth tap kdi of a volume convolution
+            const int kdi = chunk / a.nch0;
+            c = chunk - kdi * a.nch0;
+            s0 = true;
+            base = a.x0 + (int64_t)(kdi - 1) * a.slice_bytes;
+            live = (slice_mask >> kdi) & 1;
+        }
         const int64_t ld = s0 ? a.ld0 : a.ld1;
-        const int ch0 = (s0 ? chunk : chunk - a.nch0) * KRow<T>::kElems;
+        const int ch0 = c * KRow<T>::kElems;
         const int cmax = s0 ? a.C0 : a.C1;
 #pragma unroll
         for (int k = 0; k < HL; ++k) {
             const int info = hinfo[part * HL + k];
             const int ch = ch0 + (info & 7) * EPS;
-            const bool ok = info >= 0 && ch < cmax;
+            const bool ok = info >= 0 && ch < cmax && live;
             const char* src = ok ? base + ((int64_t)(info >> 3) * ld + ch) * (int64_t)sizeof(T) : reinterpret_cast<const char*>(&kZeroSlot);
             glds16_hidden(src, lds0 + buf * HBYTES + ((part * HL + k) * NT + wave * 64) * 16);
         }
@@ -241,7 +255,8 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
     for (int chunk = 0; chunk < a.nch; ++chunk) {
         // a K-row whose second half holds no real channels (C = 32 in bf16, the 27-value patch row of the first
         // convolution, the tail of a 96-channel concat) is multiplied with one k-substep instead of two
-        const int rc = chunk < a.nch0 ? a.C0 - chunk * KRow<T>::kElems : a.C1 - (chunk - a.nch0) * KRow<T>::kElems;
+        const int rc = a.depth > 0 ? a.C0 - (chunk % a.nch0) * KRow<T>::kElems
+                                   : (chunk < a.nch0 ? a.C0 - chunk * KRow<T>::kElems : a.C1 - (chunk - a.nch0) * KRow<T>::kElems);
         const int nks = rc > KRow<T>::kElems / 2 ? 2 : 1;
         const bool next_chunk = !ONE_HALO && chunk + 1 < a.nch;
         const char* hb = s_halo0 + (ONE_HALO ? 0 : (chunk & 1)) * HBYTES;
@@ -543,7 +558,9 @@ struct WgradArgs {
     int Cout, ncb;            // dy channels, output-channel blocks (of KRow elems)
     int splits, tiles_per_split;
     float* slab;              // [splits][ncb*KR][TAPS][nch*KR]
-    int depth = 0, kd = 0;    // volumes: x is read from slice n + kd of the volume that holds slice n (zero outside)
+    // volumes (depth > 0): three times the workgroups, one third per depth tap kdi; x is read from slice n + kdi - 1 of the
+    // volume that holds slice n (zero outside); slab gets a leading [3] dimension
+    int depth = 0;
 };
 
 template <typename T> __device__ __forceinline__ int wg_swz(int pix);
@@ -575,8 +592,10 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
 
     int b = blockIdx.x;
     const int split = b % a.splits; b /= a.splits;
-    const int chunk = b % a.nch;
-    const int cb = b / a.nch;
+    const int chunk = b % a.nch; b /= a.nch;
+    const int cb = b % a.ncb;
+    const int kdi = b / a.ncb;              // 0 unless a volume convolution (then 0..2)
+    const int kd = a.depth > 0 ? kdi - 1 : 0;
 
     const bool s0 = chunk < a.nch0;
     const char* xbase = s0 ? a.x0 : a.x1;
@@ -625,14 +644,14 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         const int ty = sp % a.tiles_y;
         const int n = sp / a.tiles_y;
         const int y0 = ty * TH - PAD, x0 = tx * kTW - PAD;
-        const bool slice_ok = a.depth == 0 || (unsigned)(n % a.depth + a.kd) < (unsigned)a.depth;
+        const bool slice_ok = a.depth == 0 || (unsigned)(n % a.depth + kd) < (unsigned)a.depth;
         const unsigned xdst = lds0 + st * (XBYTES + DBYTES), ddst = xdst + XBYTES;
 #pragma unroll
         for (int k = 0; k < XL; ++k) {
             const int info = xinfo[k];
             const int gy = y0 + (info >> 16), gx = x0 + ((info >> 8) & 255);
             const bool ok = info >= 0 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && slice_ok;
-            const char* src = ok ? xsrc0 + ((((int64_t)(n + a.kd) * a.H + gy) * a.W + gx) * ldx + (info & 255)) * (int64_t)sizeof(T)
+            const char* src = ok ? xsrc0 + ((((int64_t)(n + kd) * a.H + gy) * a.W + gx) * ldx + (info & 255)) * (int64_t)sizeof(T)
                                  : reinterpret_cast<const char*>(&kZeroSlot);
             // the last transfer of the halo is partial: lanes past the image's end are masked off
             if (k * kConvThreads + tid < HPIX * 8) glds16_hidden(src, xdst + (k * kConvThreads + wave * 64) * 16);
@@ -815,7 +834,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
             for (int j = 0; j < WTJ; ++j) {
                 const int co = cb * KR + (wi * WTI + i) * 16 + l15;
                 const int ci = chunk * KR + (wj * WTJ + j) * 16 + 4 * g;
-                *reinterpret_cast<float4*>(&a.slab[(((int64_t)split * co_tot + co) * TAPS + t) * cin_tot + ci]) =
+                *reinterpret_cast<float4*>(&a.slab[((((int64_t)kdi * a.splits + split) * co_tot + co) * TAPS + t) * cin_tot + ci]) =
                     make_float4(acc[t][i][j][0], acc[t][i][j][1], acc[t][i][j][2], acc[t][i][j][3]);
             }
 }
@@ -829,9 +848,9 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const f
                                                                          int taps, int cin_tot, int cout_real, int cin_real,
                                                                          int seg0, int k0_pad, float* __restrict__ dw,
                                                                          int accumulate, int ct_cout, int ct_k0, int ct_k1,
-                                                                         int ct_k2, int ct_k3, int64_t dw_so, int64_t dw_si) {
+                                                                         int ct_k2, int ct_k3, int64_t dw_so, int64_t dw_si, int nkd) {
     constexpr int OPW = 64 / P;   // outputs per wavefront
-    const int64_t total = (int64_t)cout_real * cin_real * taps;
+    const int64_t total = (int64_t)cout_real * cin_real * taps * nkd;
     const int lane = threadIdx.x & 63, p = lane / OPW, c = lane % OPW;
     const int64_t waves = (int64_t)gridDim.x * (kConvThreads / 64);
     for (int64_t w = (int64_t)blockIdx.x * (kConvThreads / 64) + (threadIdx.x >> 6); w * OPW < total; w += waves) {
@@ -839,39 +858,40 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const f
         const bool live = i < total;
         // ci fastest so that slab reads are coalesced
         const int ci = live ? (int)(i % cin_real) : 0;
-        const int64_t r = live ? i / cin_real : 0;
-        const int t = (int)(r % taps);
-        const int co = (int)(r / taps);
+        int64_t r = live ? i / cin_real : 0;
+        const int t = (int)(r % taps); r /= taps;
+        const int kdi = (int)(r % nkd);          // depth tap of a volume convolution (nkd = 3), else 0
+        const int co = (int)(r / nkd);
         const int kc = ci < seg0 ? ci : k0_pad + (ci - seg0);   // position in the K-row-padded channel space
         float s = 0.f;
         if (live)
-            for (int k = p; k < splits; k += P) s += slab[(((int64_t)k * co_tot + co) * taps + t) * cin_tot + kc];
+            for (int k = p; k < splits; k += P) s += slab[((((int64_t)kdi * splits + k) * co_tot + co) * taps + t) * cin_tot + kc];
 #pragma unroll
         for (int o = OPW; o < 64; o <<= 1) s += __shfl_xor(s, o, 64);
         if (!live || p != 0) continue;
         // ordinary convolution: OIHW [co][ci][tap].  Transposed convolution (ct_cout > 0): the weight is
         // [ci][co][4][4] and tap t of this phase is kernel element ct_k{t}.
         float* d = ct_cout > 0 ? dw + ((int64_t)ci * ct_cout + co) * 16 + (t == 0 ? ct_k0 : t == 1 ? ct_k1 : t == 2 ? ct_k2 : ct_k3)
-                               : dw + co * dw_so + ci * dw_si + t;
+                               : dw + co * dw_so + ci * dw_si + kdi * taps + t;
         *d = accumulate ? *d + s : s;
     }
 }
 
 static void launch_wgrad_reduce(hipStream_t st, const float* slab, int splits, int64_t co_tot, int taps, int cin_tot, int cout_real,
                                 int cin_real, int seg0, int k0_pad, float* dw, int accumulate, int ct_cout = 0, int k0 = 0, int k1 = 0,
-                                int k2 = 0, int k3 = 0, int64_t dw_so = 0, int64_t dw_si = 0) {
-    const int64_t total = (int64_t)cout_real * cin_real * taps;
+                                int k2 = 0, int k3 = 0, int64_t dw_so = 0, int64_t dw_si = 0, int nkd = 1) {
+    const int64_t total = (int64_t)cout_real * cin_real * taps * nkd;
     if (dw_so == 0) { dw_so = (int64_t)cin_real * taps; dw_si = taps; }   // contiguous OIHW
     if (splits >= 32) {
         int64_t grid = (total * 8 + kConvThreads - 1) / kConvThreads;
         if (grid > 16384) grid = 16384;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<8>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
-                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si);
+                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si, nkd);
     } else {
         int64_t grid = (total + kConvThreads - 1) / kConvThreads;
         if (grid > 8192) grid = 8192;
         hipLaunchKernelGGL(conv_wgrad_reduce_kernel<1>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
-                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si);
+                           cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si, nkd);
     }
 }
 
@@ -1257,15 +1277,25 @@ extern "C" int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t C
 }
 
 // ------------------------------------------------------------------------------------------------
-// Conv3d(kernel 3, stride 1, padding 1) on volumes stored slice by slice ([N*D, H, W, C]): the sum over the three
-// depth taps of a 3x3 convolution that reads the neighbouring slice (zero beyond the volume's faces), accumulated
-// in place.  Packed images: three 2-D images, one per depth tap.
+// Conv3d(kernel 3, stride 1, padding 1) on volumes stored slice by slice ([N*D, H, W, C]): ONE launch of the 3x3
+// kernel whose K dimension runs over the three depth taps -- K-rows [kdi*nch, (kdi+1)*nch) read the channels of the
+// neighbouring slice d + kdi - 1 (zero beyond the volume's faces).  Packed images: three 2-D images back to back, one
+// per depth tap, so that the kernel's (K-row, tap) step index walks straight through them.
 // ------------------------------------------------------------------------------------------------
 namespace segk {
-static size_t conv3d_slice_bytes(int dtype, int64_t Cout, int64_t Cin) { return segk_conv_packed_bytes(dtype, Cout, Cin, 9, 0); }
+// bytes of ONE depth tap's forward (fwd) or data-gradient image
+static size_t conv3d_image_bytes(int dtype, int64_t Cout, int64_t Cin, bool fwd) {
+    const int kr = krow(dtype);
+    return fwd ? (size_t)(round_up(Cin, kr) / kr * 9 * round_up(Cout, 32) * kRowBytes)
+               : (size_t)(round_up(Cout, kr) / kr * 9 * round_up(Cin, 32) * kRowBytes);
+}
 }
 
-extern "C" size_t segk_conv3d_packed_bytes(int dtype, int64_t Cout, int64_t Cin) { return 3 * conv3d_slice_bytes(dtype, Cout, Cin); }
+extern "C" size_t segk_conv3d_packed_bytes(int dtype, int64_t Cout, int64_t Cin) {
+    if (Cout <= 0 || Cin <= 0) return 0;
+    const size_t f = conv3d_image_bytes(dtype, Cout, Cin, true), b = conv3d_image_bytes(dtype, Cout, Cin, false);
+    return 3 * (f > b ? f : b);
+}
 
 extern "C" int segk_conv3d_pack(const float* w, int64_t Cout, int64_t Cin, int dtype, void* wf, void* wb, int dev, void* stream) {
     SEGK_REQUIRE(w && (wf || wb) && Cin > 0 && Cout > 0, SEGK_EINVAL, "conv3d_pack: bad arguments");
@@ -1273,14 +1303,14 @@ extern "C" int segk_conv3d_pack(const float* w, int64_t Cout, int64_t Cin, int d
     SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "conv3d_pack: packed buffers must be 16-byte aligned");
     SEGK_HIP(use_device(dev));
     const int kr = krow(dtype);
-    const size_t per = conv3d_slice_bytes(dtype, Cout, Cin);
+    const size_t per_f = conv3d_image_bytes(dtype, Cout, Cin, true), per_b = conv3d_image_bytes(dtype, Cout, Cin, false);
     const int64_t slots = ((wf ? round_up(Cin, kr) / kr * round_up(Cout, 32) : 0) + (wb ? round_up(Cout, kr) / kr * round_up(Cin, 32) : 0)) * 9 * 8;
     int64_t grid = (slots + kConvThreads - 1) / kConvThreads;
     if (grid > 4096) grid = 4096;
     for (int kd = 0; kd < 3; ++kd) {
         // forward image kd multiplies slice d + kd - 1; the data gradient reads dy at d - (kd - 1): its image sits at 2 - kd
-        char* f = wf ? (char*)wf + kd * per : nullptr;
-        char* b = wb ? (char*)wb + (2 - kd) * per : nullptr;
+        char* f = wf ? (char*)wf + kd * per_f : nullptr;
+        char* b = wb ? (char*)wb + (2 - kd) * per_b : nullptr;
         SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3((unsigned)grid), dim3(kConvThreads), 0, (hipStream_t)stream,
                                                          w + kd * 9, (int)Cout, (int)Cin, 9, (int)Cin, f, b, Cin * 27, (int64_t)27));
         SEGK_LAUNCH_CHECK();
@@ -1298,31 +1328,38 @@ extern "C" int segk_conv3d_fwd(int dtype, const void* x, int64_t ldx, int64_t Ci
     const int kr = krow(dtype);
     ConvArgs a;
     a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
-    a.nch0 = a.nch = (int)(round_up(Cin, kr) / kr);
+    a.nch0 = (int)(round_up(Cin, kr) / kr);
+    a.nch = 3 * a.nch0;                                   // the three depth taps are consecutive stretches of K
     a.N = (int)(N * D); a.H = (int)H; a.W = (int)W; a.depth = (int)D;
+    a.slice_bytes = H * W * ldx * (int64_t)esize(dtype);
     a.vin = a.vout = identity_view((int)H, (int)W);
     a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.w = (const char*)w_packed;
     a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
     a.bias = nullptr; a.y = (char*)y; a.ldy = ldy; a.mask = nullptr; a.ld_mask = 0; a.mask_c = 0; a.relu = 0;
+    a.accumulate = (flags >> 1) & 1;
     const int bn = pick_bn(a.cout_pad);
     SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv3d_fwd: grid too large");
-    const size_t per = conv3d_slice_bytes(dtype, Cout, Cin);
-    // centre tap first (every slice has one, so it may overwrite); the two neighbours accumulate, and workgroups whose
-    // neighbour slice lies outside the volume exit at once
-    static const int order[3] = {1, 0, 2};
-    for (int i = 0; i < 3; ++i) {
-        const int kd = order[i];
-        a.kd = kd - 1;
-        a.w = (const char*)w_packed + kd * per;
-        a.accumulate = (i > 0 || ((flags >> 1) & 1)) ? 1 : 0;
-        launch_fwd_any(dtype, 9, a, bn, (hipStream_t)stream);
-        SEGK_LAUNCH_CHECK();
-    }
+    launch_fwd_any(dtype, 9, a, bn, (hipStream_t)stream);
+    SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 
+namespace segk {
+static int conv3d_wgrad_splits(int dtype, int64_t Cin, int64_t ND, int64_t H, int64_t W, int64_t Cout) {
+    const int kr = krow(dtype);
+    const int64_t ntiles = ND * ((H + 7) / 8) * ((W + kTW - 1) / kTW);
+    // three times the workgroups of the 2-D case for the same resident round: a third of the pixel splits
+    return wgrad_splits(ntiles, 3 * ((Cout + kr - 1) / kr), round_up(Cin, kr) / kr);
+}
+}
+
 extern "C" size_t segk_conv3d_wgrad_workspace(int dtype, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t Cout) {
-    return segk_conv_wgrad_workspace(dtype, 9, Cin, 0, N * D, H, W, Cout);
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0) return 0;
+    const int kr = krow(dtype);
+    const int64_t nch = round_up(Cin, kr) / kr, ncb = (Cout + kr - 1) / kr;
+    const int s = conv3d_wgrad_splits(dtype, Cin, N * D, H, W, Cout);
+    return align_up((size_t)3 * s * ncb * kr * 9 * nch * kr * sizeof(float), 256);
 }
 
 extern "C" int segk_conv3d_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W,
@@ -1343,18 +1380,15 @@ extern "C" int segk_conv3d_wgrad(int dtype, const void* x, int64_t ldx, int64_t 
     a.dy = (const char*)dy; a.ldy = ld_dy; a.Cout = (int)Cout; a.ncb = (int)((Cout + kr - 1) / kr);
     a.vdy = identity_view((int)H, (int)W);
     const int64_t ntiles = (int64_t)a.N * a.tiles_x * a.tiles_y;
-    a.splits = wgrad_splits(ntiles, a.ncb, a.nch);
+    a.splits = conv3d_wgrad_splits(dtype, Cin, N * D, H, W, Cout);
     a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
     a.slab = (float*)workspace;
-    const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
-    for (int kd = 0; kd < 3; ++kd) {
-        a.kd = kd - 1;
-        launch_wgrad_any(dtype, 9, a, grid, st, Cout, Cin);
-        SEGK_LAUNCH_CHECK();
-        // dw is [Cout][Cin][3][3][3]: depth tap kd is a 9-element run inside the 27 of a (co, ci) pair
-        launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, 9, a.nch * kr, (int)Cout, (int)Cin, (int)Cin,
-                            a.nch0 * kr, dw + kd * 9, (flags >> 1) & 1, 0, 0, 0, 0, 0, Cin * 27, 27);
-        SEGK_LAUNCH_CHECK();
-    }
+    // one launch for the three depth taps (slab [3][splits]...), one reduction that writes dw[Cout][Cin][3][3][3]
+    const unsigned grid = (unsigned)((int64_t)3 * a.ncb * a.nch * a.splits);
+    launch_wgrad_any(dtype, 9, a, grid, st, Cout, Cin);
+    SEGK_LAUNCH_CHECK();
+    launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, 9, a.nch * kr, (int)Cout, (int)Cin, (int)Cin,
+                        a.nch0 * kr, dw, (flags >> 1) & 1, 0, 0, 0, 0, 0, Cin * 27, 27, 3);
+    SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

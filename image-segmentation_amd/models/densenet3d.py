@@ -108,7 +108,7 @@ class DenseNet(SegkNet):
             raise NotImplementedError("dropout inside the dense layers is not implemented on the HIP path (reference default drop_rate=0)")
         f = prefix + "features."
         N = v.act.N // D
-        y, D = rt.conv_patches(v, D, f + "conv1.weight", self.stem["kernel"], self.stem["stride"], self.stem["pad"], need_dx)
+        y, D = rt.conv_patches(v, D, f + "conv1.weight", self.stem["kernel"], self.stem["stride"], self.stem["pad"], need_dx, stats=True)
         H, W = y.act.H, y.act.W
         c_in, c_out = self.block_io[0]
         if self.no_max_pool:

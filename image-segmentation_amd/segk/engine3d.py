@@ -22,7 +22,7 @@ class Runtime3D(Runtime):
         return Var(ops.nchw_to_nhwc(x2, self.dtype, C=8)), D
 
     # ---------------------------------------------------------------- strided stem convolutions
-    def conv_patches(self, v, D, wname, kernel, stride, pad, need_dx):
+    def conv_patches(self, v, D, wname, kernel, stride, pad, need_dx, stats=False):
         """Conv3d(bias=False) with an arbitrary kernel/stride on a few-channel input: patch gather + 1x1 convolution.
         Output channels are stored rounded up to 8 (extra ones exactly zero).  -> (Var, Do)"""
         w = self.p[wname]
@@ -35,7 +35,7 @@ class Runtime3D(Runtime):
         w1[:Cout, :K, 0, 0] = w.detach().permute(0, 2, 3, 4, 1).reshape(Cout, K)     # tap-major, channel-minor columns
         wf, wb = ops.conv_pack(w1, self.dtype, want_bwd=self.need_grad and need_dx)
         y = Var(self.new(patches.N, patches.H, patches.W, cs))
-        ops.conv_fwd(patches, wf, cs, y.act, taps=1)
+        ops.conv_fwd(patches, wf, cs, y.act, taps=1, stat_partials=self._stat_buffer(y, stats))
 
         def bwd():
             dy = self.grad_of(y.act)
@@ -53,14 +53,14 @@ class Runtime3D(Runtime):
         return y, Do
 
     # ---------------------------------------------------------------- 1x1x1 and 3x3x3 convolutions
-    def conv1x1(self, x, wname, out=None):
+    def conv1x1(self, x, wname, out=None, stats=False):
         w = self.p[wname]
         Cout, Cin = w.shape[0], w.shape[1]
         a = x.act
         assert a.C == Cin
         wf, wb = self._pack(wname, view=(Cout, Cin, 1, 1))
         y = Var(out or self.new(a.N, a.H, a.W, Cout))
-        ops.conv_fwd(a, wf, Cout, y.act, taps=1)
+        ops.conv_fwd(a, wf, Cout, y.act, taps=1, stat_partials=self._stat_buffer(y, stats))
 
         def bwd():
             dy = self.grad_of(y.act)
@@ -135,7 +135,7 @@ class Runtime3D(Runtime):
             xin = Var(Act(feat.buf, feat.c0, c))
             xin.ready = True
             h = self.bn_relu(xin, lp + "norm1")
-            h = self.conv1x1(h, lp + "conv1.weight")
+            h = self.conv1x1(h, lp + "conv1.weight", stats=True)      # its epilogue feeds norm2's batch statistics
             h = self.bn_relu(h, lp + "norm2")
             self.conv3d(h, D, lp + "conv2.weight", out=Act(feat.buf, feat.c0 + c, growth))
             c += growth

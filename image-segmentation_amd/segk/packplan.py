@@ -30,9 +30,13 @@ class PackPlan:
         Cout, Cin = w.shape[0], w.shape[1]
         p = lambda t, off=0: 0 if t is None else t.data_ptr() + off   # noqa: E731
         if w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3):
-            per = query("segk_conv_packed_bytes", ops.dt(dtype), Cout, Cin, 9, 0)
+            # the three depth-tap images lie back to back (forward: K = Cin, rows = Cout; data gradient: the other way round)
+            kr = query("segk_conv_krow", ops.dt(dtype))
+            up = lambda v, m: (v + m - 1) // m * m   # noqa: E731
+            per_f = up(Cin, kr) // kr * 9 * up(Cout, 32) * 128
+            per_b = up(Cout, kr) // kr * 9 * up(Cin, 32) * 128
             for kd in range(3):
-                self.descs.append((w.data_ptr() + kd * 9 * 4, p(wf, kd * per), p(wb, (2 - kd) * per), Cout, Cin, 9, Cin, Cin * 27, 27))
+                self.descs.append((w.data_ptr() + kd * 9 * 4, p(wf, kd * per_f), p(wb, (2 - kd) * per_b), Cout, Cin, 9, Cin, Cin * 27, 27))
         else:
             taps = w[0, 0].numel()
             self.descs.append((w.data_ptr(), p(wf), p(wb), Cout, Cin, taps, seg0 or Cin, Cin * taps, taps))

@@ -192,8 +192,9 @@ int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t
  * A batch of volumes [N, C, D, H, W] is stored slice by slice: [N*D, H, W, ld], channels innermost, so the
  * channel-wise entry points above (norm_*, conv with taps=1, colsum, copy_slice) take it with N*D as the batch.
  *
- * Conv3d(kernel 3, stride 1, padding 1, bias=False): three 3x3 convolutions, one per depth tap, each reading the
- * neighbouring slice of the same volume (zero beyond its faces) and accumulating in place.
+ * Conv3d(kernel 3, stride 1, padding 1, bias=False): ONE launch of the 3x3 MFMA kernel whose K dimension runs over the
+ * three depth taps, each reading the neighbouring slice of the same volume (zero beyond its faces); fp32 accumulation
+ * over all 27 taps.  The weight gradient is one launch for the three depth taps plus one reduction.
  * replaces: nn.Conv3d(bn_size*growth_rate, growth_rate, kernel_size=3, stride=1, padding=1, bias=False) forward and
  *           backward (models/densenet3d.py:27-32).  w: the module's fp32 [Cout, Cin, 3, 3, 3] weight.
  * segk_conv3d_fwd with the `wb` image on dy (Cout channels) yields dx (Cin channels).  flags bit1: accumulate.
