@@ -32,7 +32,19 @@ struct Geo3 {
 template <typename T>
 __global__ __launch_bounds__(kVThreads) void im2col3d_kernel(const T* __restrict__ x, int64_t ldx, Geo3 g, T* __restrict__ out,
                                                              int64_t ldo, int Kp) {
+    // column -> (depth tap, row tap, column tap, channel) once per workgroup (the integer divisions dominate otherwise):
+    // a << 24 | b << 16 | e << 8 | c, or -1 for the zero columns behind K
+    extern __shared__ int col_info[];
     const int K = g.C * g.kd * g.kh * g.kw, groups = Kp / 8;
+    for (int k = threadIdx.x; k < Kp; k += kVThreads) {
+        int r = k;
+        const int c = r % g.C; r /= g.C;
+        const int e = r % g.kw; r /= g.kw;
+        const int b = r % g.kh;
+        const int a = r / g.kh;
+        col_info[k] = k < K ? ((a << 24) | (b << 16) | (e << 8) | c) : -1;
+    }
+    __syncthreads();
     const int64_t items = (int64_t)g.N * g.Do * g.Ho * g.Wo * groups;
     for (int64_t i = (int64_t)blockIdx.x * kVThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kVThreads) {
         const int gr = (int)(i % groups);
@@ -42,21 +54,15 @@ __global__ __launch_bounds__(kVThreads) void im2col3d_kernel(const T* __restrict
         const int oh = (int)(p % g.Ho); p /= g.Ho;
         const int od = (int)(p % g.Do);
         const int64_t n = p / g.Do;
+        const int d0 = od * g.sd - g.pd, y0 = oh * g.sh - g.ph, x0 = ow * g.sw - g.pw;
+        const T* xn = x + n * g.D * g.H * (int64_t)g.W * ldx;
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            int k = gr * 8 + j;
-            float val = 0.f;
-            if (k < K) {
-                const int c = k % g.C; k /= g.C;
-                const int e = k % g.kw; k /= g.kw;
-                const int b = k % g.kh;
-                const int a = k / g.kh;
-                const int d = od * g.sd - g.pd + a, y = oh * g.sh - g.ph + b, xx = ow * g.sw - g.pw + e;
-                if ((unsigned)d < (unsigned)g.D && (unsigned)y < (unsigned)g.H && (unsigned)xx < (unsigned)g.W)
-                    val = Elem<T>::to_f(x[(((n * g.D + d) * g.H + y) * g.W + xx) * ldx + c]);
-            }
-            v[j] = val;
+            const int info = col_info[gr * 8 + j];
+            const int d = d0 + (info >> 24), y = y0 + ((info >> 16) & 255), xx = x0 + ((info >> 8) & 255);
+            const bool ok = info >= 0 && (unsigned)d < (unsigned)g.D && (unsigned)y < (unsigned)g.H && (unsigned)xx < (unsigned)g.W;
+            v[j] = ok ? Elem<T>::to_f(xn[(((int64_t)d * g.H + y) * g.W + xx) * ldx + (info & 255)]) : 0.f;
         }
         Elem<T>::store8(out + vox * ldo + gr * 8, v);
     }
@@ -323,10 +329,11 @@ extern "C" int segk_im2col3d(int dtype, const void* x, int64_t ldx, int64_t C, i
     if (int rc = make_geo("im2col3d", N, C, D, H, W, kernel, stride, pad, &g)) return rc;
     SEGK_CHECK_VOL("im2col3d(x)", x, ldx, 8, dtype);
     SEGK_CHECK_VOL("im2col3d(patches)", patches, ld_patches, Kp, dtype);
-    SEGK_REQUIRE(Kp >= C * g.kd * g.kh * g.kw, SEGK_ESHAPE, "im2col3d: Kp %lld < C*kd*kh*kw", (long long)Kp);
+    SEGK_REQUIRE(Kp >= C * g.kd * g.kh * g.kw && Kp <= 8192, SEGK_ESHAPE, "im2col3d: Kp %lld must cover C*kd*kh*kw and be at most 8192", (long long)Kp);
+    SEGK_REQUIRE(g.kd < 128 && g.kh < 256 && g.kw < 256, SEGK_ESHAPE, "im2col3d: kernel extent too large");
     SEGK_HIP(use_device(dev));
     const int64_t items = (int64_t)g.N * g.Do * g.Ho * g.Wo * (Kp / 8);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((im2col3d_kernel<T>), dim3(vgrid(items, 65536)), dim3(kVThreads), 0, (hipStream_t)stream,
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((im2col3d_kernel<T>), dim3(vgrid(items, 16384)), dim3(kVThreads), (size_t)Kp * sizeof(int), (hipStream_t)stream,
                                                      (const T*)x, ldx, g, (T*)patches, ld_patches, (int)Kp));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
