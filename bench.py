@@ -223,8 +223,15 @@ def main():
                        "final_loss": round(final_loss, 5)},
         }
         if timer:
-            fwd = sum(a.elapsed_time(b) for k, a, b in timer if k == "conv_fwd")
-            wg = sum(a.elapsed_time(b) for k, a, b in timer if k == "conv_wgrad")
+            fwd = sum(a.elapsed_time(b) for k, a, b, _, _ in timer if k == "conv_fwd")
+            wg = sum(a.elapsed_time(b) for k, a, b, _, _ in timer if k == "conv_wgrad")
+            # the same events per kernel family, with the FLOP each launch actually multiplied (the 27-value patch row of the
+            # first convolution counts as its 32 stored channels, so the sum is 0.1 % above the algorithmic figure)
+            fam = {}
+            for k, a, b, fl, variant in timer:
+                name = "conv_wgrad_kernel" if k == "conv_wgrad" else f"conv_fwd_kernel[{variant}]"
+                ms_, fl_, n_ = fam.get(name, (0.0, 0.0, 0))
+                fam[name] = (ms_ + a.elapsed_time(b), fl_ + fl, n_ + 1)
             conv_ms = (fwd + wg) / args.steps
             achieved = gflop * args.batch / conv_ms        # GFLOP / ms = TFLOP/s
             peak = MFMA_PEAK_TFLOPS[args.dtype]
@@ -241,7 +248,10 @@ def main():
                                "kernel": "conv_fwd_kernel + conv_wgrad_kernel (all MFMA convolution launches of a step)",
                                "launches_per_step": len(timer) // args.steps, "conv_ms_per_step": round(conv_ms, 3),
                                "fwd_dgrad_ms": round(fwd / args.steps, 3), "wgrad_ms": round(wg / args.steps, 3),
-                               "whole_step_mfma_frac": round(gflop * args.batch / ms / peak, 4)}
+                               "whole_step_mfma_frac": round(gflop * args.batch / ms / peak, 4),
+                               "by_kernel": {name: {"launches_per_step": n_ // args.steps, "ms_per_step": round(ms_ / args.steps, 3),
+                                                    "achieved": round(fl_ / ms_ / 1e9, 1), "frac": round(fl_ / ms_ / 1e9 / peak, 4)}
+                                             for name, (ms_, fl_, n_) in sorted(fam.items()) if ms_ > 0}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_detectmid(args.depth, args.side) if args.model == "detectmid" else cpu_baseline(n_classes)
         print(json.dumps(out), flush=True)

@@ -72,13 +72,14 @@ def _env(t):
 _workspaces = {}
 
 # Optional per-launch timing of the MFMA convolutions (bench.py's roofline leg): a list that receives
-# (kind, start_event, end_event) for every conv launch, recorded on the stream the kernel runs on.
+# (kind, start_event, end_event, algorithmic FLOP, kernel variant) for every conv launch, recorded on the stream the
+# kernel runs on.
 CONV_TIMER = None
 
 
 class _Timed:
-    def __init__(self, kind):
-        self.kind = kind
+    def __init__(self, kind, flops=0.0, variant=""):
+        self.kind, self.flops, self.variant = kind, flops, variant
 
     def __enter__(self):
         if CONV_TIMER is not None:
@@ -89,7 +90,7 @@ class _Timed:
         if CONV_TIMER is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            CONV_TIMER.append((self.kind, self.e0, e1))
+            CONV_TIMER.append((self.kind, self.e0, e1, self.flops, self.variant))
 
 
 def workspace(nbytes, device):
@@ -177,7 +178,8 @@ def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, a
     assert o0.C + (o1.C if o1 else 0) == Cout and (o0.N, o0.H, o0.W) == (a.N, a.H, a.W) and o0.dtype == a.dtype
     dev, st = _env(a.buf)
     flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (4 if accumulate1 else 0)
-    with _Timed("conv_fwd"):
+    cin = a.C + (b.C if b else 0)
+    with _Timed("conv_fwd", 2.0 * a.P * Cout * cin * taps, "128-wide" if (Cout + 31) // 32 * 32 % 128 == 0 else "narrow"):
         call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
              a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), o0.ptr, o0.ld, o1.ptr if o1 else None, o1.ld if o1 else 0,
              o0.C if o1 else 0, mask.ptr if mask else None, mask.ld if mask else 0, mask.C if mask else 0, _p(stat_partials), flags,
@@ -196,7 +198,7 @@ def conv_wgrad(x, dy, dw, taps=9, cin_real=None, accumulate=False):
     d = dt(a.dtype)
     nbytes = query("segk_conv_wgrad_workspace", d, taps, a.C, b.C if b else 0, a.N, a.H, a.W, Cout)
     ws = workspace(nbytes, a.device)
-    with _Timed("conv_wgrad"):
+    with _Timed("conv_wgrad", 2.0 * a.P * Cout * cin * taps):
         call("segk_conv_wgrad", d, taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0, a.N, a.H,
              a.W, dy.ptr, dy.ld, Cout, cin_real, dw.data_ptr(), ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
     return dw
@@ -218,7 +220,7 @@ def convt_fwd(x, wf, Cout, out, bias=None, relu=False):
     """out [N,2H,2W,Cout] = ConvTranspose2d(4, stride 2, padding 1)(x) (+bias, +ReLU)."""
     assert out.C == Cout and (out.N, out.H, out.W) == (x.N, 2 * x.H, 2 * x.W) and out.dtype == x.dtype
     dev, st = _env(x.buf)
-    with _Timed("conv_fwd"):
+    with _Timed("conv_fwd", 2.0 * x.P * x.C * Cout * 16, "transposed"):
         call("segk_convt_fwd", dt(x.dtype), x.ptr, x.ld, x.C, x.N, x.H, x.W, wf.data_ptr(), Cout, _p(bias), out.ptr, out.ld,
              RELU if relu else 0, dev, st)
     return out
@@ -228,7 +230,7 @@ def convt_dgrad(dy, wb, dx, mask=None, accumulate=False):
     """dx [N,H,W,Cin] from dy [N,2H,2W,Cout]; mask: forward activation whose ReLU gates dx."""
     assert (dy.N, dy.H, dy.W) == (dx.N, 2 * dx.H, 2 * dx.W)
     dev, st = _env(dy.buf)
-    with _Timed("conv_fwd"):
+    with _Timed("conv_fwd", 2.0 * dx.P * dx.C * dy.C * 16, "transposed"):
         call("segk_convt_dgrad", dt(dy.dtype), dy.ptr, dy.ld, dy.C, dx.N, dx.H, dx.W, wb.data_ptr(), dx.C, dx.ptr, dx.ld,
              mask.ptr if mask else None, mask.ld if mask else 0, ACCUM if accumulate else 0, dev, st)
     return dx
@@ -240,7 +242,7 @@ def convt_wgrad(x, dy, dw, accumulate=False):
     dev, st = _env(x.buf)
     d = dt(x.dtype)
     ws = workspace(query("segk_convt_wgrad_workspace", d, x.C, dy.C, x.N, x.H, x.W), x.device)
-    with _Timed("conv_wgrad"):
+    with _Timed("conv_wgrad", 2.0 * x.P * x.C * dy.C * 16):
         call("segk_convt_wgrad", d, x.ptr, x.ld, x.C, x.N, x.H, x.W, dy.ptr, dy.ld, dy.C, dw.data_ptr(),
              ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
     return dw
@@ -398,7 +400,7 @@ def conv3d_fwd(x, D, w_packed, out, accumulate=False):
     """out = Conv3d(3, padding 1)(x) with the forward images, or dx from dy with the data-gradient images."""
     assert x.N % D == 0 and (out.N, out.H, out.W) == (x.N, x.H, x.W) and out.dtype == x.dtype
     dev, st = _env(x.buf)
-    with _Timed("conv_fwd"):
+    with _Timed("conv_fwd", 2.0 * x.P * x.C * out.C * 27, "128-wide" if (out.C + 31) // 32 * 32 % 128 == 0 else "narrow"):
         call("segk_conv3d_fwd", dt(x.dtype), x.ptr, x.ld, x.C, x.N // D, D, x.H, x.W, w_packed.data_ptr(), out.C, out.ptr, out.ld,
              ACCUM if accumulate else 0, dev, st)
     return out
@@ -409,7 +411,7 @@ def conv3d_wgrad(x, D, dy, dw, accumulate=False):
     dev, st = _env(x.buf)
     d = dt(x.dtype)
     ws = workspace(query("segk_conv3d_wgrad_workspace", d, x.C, x.N // D, D, x.H, x.W, dy.C), x.device)
-    with _Timed("conv_wgrad"):
+    with _Timed("conv_wgrad", 2.0 * x.P * x.C * dy.C * 27):
         call("segk_conv3d_wgrad", d, x.ptr, x.ld, x.C, x.N // D, D, x.H, x.W, dy.ptr, dy.ld, dy.C, dw.data_ptr(),
              ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
     return dw
