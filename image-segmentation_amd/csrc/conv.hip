@@ -251,6 +251,14 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 
     // per-lane LDS read bases; everything tap-dependent below is a compile-time offset (taps are unrolled)
     const int co_l = wco * WCO + l15, hp_l = wpx * NJ * HW_ + l15;
+    // Pixel-fragment reads: halo pixel hp = hp_l + c with c = (row + ky) * HW_ + kx known at compile time, swizzled slot
+    // (ks*4 + g) ^ (hp & 7).  Only c & 7 enters the swizzle, so the eight possible byte offsets per k-substep are
+    // computed once per lane and every read is base[c & 7] + an immediate -- no address arithmetic inside the tap loop.
+    int boff[2][8];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) boff[ks][c] = hp_l * kRowBytes + (((ks * 4 + g) ^ ((hp_l + c) & 7)) << 4);
 
     for (int chunk = 0; chunk < a.nch; ++chunk) {
         // a K-row whose second half holds no real channels (C = 32 in bf16, the 27-value patch row of the first
@@ -274,8 +282,13 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
             const int slot = ks * 4 + g;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int hp = hp_l + (j + tap_ky(tap)) * HW_ + tap_kx(tap);
-                fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
+                if constexpr (TAPS != 4) {
+                    const int c = (j + tap_ky(tap)) * HW_ + tap_kx(tap);       // a constant once the tap loop is unrolled
+                    fb[j] = *reinterpret_cast<const Slot*>(hb + boff[ks][c & 7] + c * kRowBytes);
+                } else {
+                    const int hp = hp_l + (j + tap_ky(tap)) * HW_ + tap_kx(tap);
+                    fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + ((slot ^ (hp & 7)) << 4));
+                }
             }
         };
         auto load_a = [&](const char* wb, int ks, Slot (&fa)[NI]) {
