@@ -58,9 +58,9 @@ struct ConvArgs {
     int xcd_remap = 1;
     const char* mask; int64_t ld_mask; int mask_c;   // output channels below mask_c are zeroed where mask <= 0
     int relu, accumulate;
-    // volumes (depth > 0): image n is slice n % depth of its volume, and the K dimension runs over the three depth taps:
-    // K-row chunk = kdi * nch0 + c reads channels c of slice n + kdi - 1 (zero beyond the volume's faces)
-    int depth = 0;
+    // volumes (depth > 0): image n is slice n % depth of its volume, and the K dimension runs over nkd (odd, <= 7) depth
+    // taps: K-row chunk = kdi * nch0 + c reads channels c of slice n + kdi - nkd/2 (zero beyond the volume's faces)
+    int depth = 0, nkd = 3;
     int64_t slice_bytes = 0;          // bytes between consecutive slices of the input
     float* stat_part = nullptr;       // optional [N*tiles][pixel-wave][2][Cout]: per-wave sum / sum of squares of the stored output
 };
@@ -180,10 +180,10 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
     const int n = sp / a.tiles_y;
     const int y0 = ty * TH, x0 = tx * kTW;
     // depth taps of a volume convolution: bit kdi set = slice n + kdi - 1 lies inside the volume
-    int slice_mask = 7;
+    int slice_mask = 0;
     if (a.depth > 0) {
-        const int d = n % a.depth;
-        slice_mask = (d > 0 ? 1 : 0) | 2 | (d + 1 < a.depth ? 4 : 0);
+        const int d = n % a.depth - a.nkd / 2;
+        for (int k = 0; k < a.nkd; ++k) slice_mask |= ((unsigned)(d + k) < (unsigned)a.depth ? 1 : 0) << k;
     }
 
     // ---- staging: global -> LDS by DMA (no registers, stays in flight behind the MFMAs) -------------
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
             const int kdi = chunk / a.nch0;
             c = chunk - kdi * a.nch0;
             s0 = true;
-            base = a.x0 + (int64_t)(kdi - 1) * a.slice_bytes;
+            base = a.x0 + (int64_t)(kdi - a.nkd / 2) * a.slice_bytes;
             live = (slice_mask >> kdi) & 1;
         }
         const int64_t ld = s0 ? a.ld0 : a.ld1;
@@ -571,9 +571,9 @@ struct WgradArgs {
     int Cout, ncb;            // dy channels, output-channel blocks (of KRow elems)
     int splits, tiles_per_split;
     float* slab;              // [splits][ncb*KR][TAPS][nch*KR]
-    // volumes (depth > 0): three times the workgroups, one third per depth tap kdi; x is read from slice n + kdi - 1 of the
-    // volume that holds slice n (zero outside); slab gets a leading [3] dimension
-    int depth = 0;
+    // volumes (depth > 0): nkd times the workgroups, one share per depth tap kdi; x is read from slice n + kdi - nkd/2 of
+    // the volume that holds slice n (zero outside); slab gets a leading [nkd] dimension
+    int depth = 0, nkd = 3;
 };
 
 template <typename T> __device__ __forceinline__ int wg_swz(int pix);
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
     const int chunk = b % a.nch; b /= a.nch;
     const int cb = b % a.ncb;
     const int kdi = b / a.ncb;              // 0 unless a volume convolution (then 0..2)
-    const int kd = a.depth > 0 ? kdi - 1 : 0;
+    const int kd = a.depth > 0 ? kdi - a.nkd / 2 : 0;
 
     const bool s0 = chunk < a.nch0;
     const char* xbase = s0 ? a.x0 : a.x1;
@@ -1402,6 +1402,130 @@ extern "C" int segk_conv3d_wgrad(int dtype, const void* x, int64_t ldx, int64_t 
     SEGK_LAUNCH_CHECK();
     launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, 9, a.nch * kr, (int)Cout, (int)Cin, (int)Cin,
                         a.nch0 * kr, dw, (flags >> 1) & 1, 0, 0, 0, 0, 0, Cin * 27, 27, 3);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conv3d with kernel (kd, 1, 1), stride 1, padding (kd/2, 0, 0) over slice-major volumes: the depth half of a
+// factorised strided stem convolution -- the (kh, kw) window is gathered per slice into patch rows once
+// (segk_im2col3d with a depth extent of 1), and this convolution sums the kd neighbouring slices' patch rows.
+// One launch of the 1x1 kernel whose K loop runs over the depth taps.  w: fp32 [Cout][Cin][kd].
+// ------------------------------------------------------------------------------------------------
+namespace segk {
+static size_t convd_image_bytes(int dtype, int64_t Cout, int64_t Cin, bool fwd) {
+    const int kr = krow(dtype);
+    return fwd ? (size_t)(round_up(Cin, kr) / kr * round_up(Cout, 32) * kRowBytes)
+               : (size_t)(round_up(Cout, kr) / kr * round_up(Cin, 32) * kRowBytes);
+}
+static int check_convd(const char* who, int64_t kd) {
+    if (kd < 1 || kd > 7 || kd % 2 == 0) return fail(SEGK_ESHAPE, "%s: depth extent %lld must be 1, 3, 5 or 7", who, (long long)kd);
+    return SEGK_OK;
+}
+static int convd_wgrad_splits(int dtype, int64_t Cin, int64_t ND, int64_t H, int64_t W, int64_t Cout, int64_t kd) {
+    const int kr = krow(dtype);
+    const int64_t ntiles = ND * ((H + 7) / 8) * ((W + kTW - 1) / kTW);
+    return wgrad_splits(ntiles, kd * ((Cout + kr - 1) / kr), round_up(Cin, kr) / kr);
+}
+}
+
+extern "C" size_t segk_convd_packed_bytes(int dtype, int64_t Cout, int64_t Cin, int64_t kd) {
+    if (Cout <= 0 || Cin <= 0 || kd < 1) return 0;
+    const size_t f = convd_image_bytes(dtype, Cout, Cin, true), b = convd_image_bytes(dtype, Cout, Cin, false);
+    return (size_t)kd * (f > b ? f : b);
+}
+
+extern "C" int segk_convd_pack(const float* w, int64_t Cout, int64_t Cin, int64_t kd, int dtype, void* wf, void* wb, int dev, void* stream) {
+    SEGK_REQUIRE(w && (wf || wb) && Cin > 0 && Cout > 0, SEGK_EINVAL, "convd_pack: bad arguments");
+    if (int rc = check_convd("convd_pack", kd)) return rc;
+    SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "convd_pack: unknown dtype");
+    SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "convd_pack: packed buffers must be 16-byte aligned");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    const size_t per_f = convd_image_bytes(dtype, Cout, Cin, true), per_b = convd_image_bytes(dtype, Cout, Cin, false);
+    const int64_t slots = ((wf ? round_up(Cin, kr) / kr * round_up(Cout, 32) : 0) + (wb ? round_up(Cout, kr) / kr * round_up(Cin, 32) : 0)) * 8;
+    int64_t grid = (slots + kConvThreads - 1) / kConvThreads;
+    if (grid > 4096) grid = 4096;
+    for (int a = 0; a < kd; ++a) {
+        // forward image a multiplies slice d + a - kd/2; the data gradient reads dy at d - (a - kd/2): its image sits at kd-1-a
+        char* f = wf ? (char*)wf + a * per_f : nullptr;
+        char* b = wb ? (char*)wb + (kd - 1 - a) * per_b : nullptr;
+        SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_kernel<T>), dim3((unsigned)grid), dim3(kConvThreads), 0, (hipStream_t)stream,
+                                                         w + a, (int)Cout, (int)Cin, 1, (int)Cin, f, b, Cin * kd, kd));
+        SEGK_LAUNCH_CHECK();
+    }
+    return SEGK_OK;
+}
+
+extern "C" int segk_convd_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t kd,
+                              const void* w_packed, int64_t Cout, void* y, int64_t ldy, float* stat_partials, int flags, int dev,
+                              void* stream) {
+    if (int rc = check_convt("convd_fwd(x)", dtype, x, ldx, Cin)) return rc;
+    if (int rc = check_convt("convd_fwd(y)", dtype, y, ldy, Cout)) return rc;
+    if (int rc = check_convd("convd_fwd", kd)) return rc;
+    SEGK_REQUIRE(w_packed && aligned16(w_packed) && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28), SEGK_ESHAPE,
+                 "convd_fwd: bad arguments");
+    SEGK_REQUIRE(!stat_partials || (aligned16(stat_partials) && !(flags & 2)), SEGK_EINVAL, "convd_fwd: statistics need a non-accumulating call");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    ConvArgs a;
+    a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
+    a.nch0 = (int)(round_up(Cin, kr) / kr);
+    a.nkd = (int)kd;
+    a.nch = a.nkd * a.nch0;
+    a.N = (int)(N * D); a.H = (int)H; a.W = (int)W; a.depth = (int)D;
+    a.slice_bytes = H * W * ldx * (int64_t)esize(dtype);
+    a.vin = a.vout = identity_view((int)H, (int)W);
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.w = (const char*)w_packed;
+    a.Cout = (int)Cout; a.cout_pad = (int)round_up(Cout, 32);
+    a.bias = nullptr; a.y = (char*)y; a.ldy = ldy; a.mask = nullptr; a.ld_mask = 0; a.mask_c = 0; a.relu = 0;
+    a.accumulate = (flags >> 1) & 1;
+    a.stat_part = stat_partials;
+    const int bn = pick_bn(a.cout_pad);
+    SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "convd_fwd: grid too large");
+    launch_fwd_any(dtype, 1, a, bn, (hipStream_t)stream);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" size_t segk_convd_wgrad_workspace(int dtype, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t Cout, int64_t kd) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Cout <= 0 || Cin <= 0 || kd < 1) return 0;
+    const int kr = krow(dtype);
+    const int64_t nch = round_up(Cin, kr) / kr, ncb = (Cout + kr - 1) / kr;
+    const int s = convd_wgrad_splits(dtype, Cin, N * D, H, W, Cout, kd);
+    return align_up((size_t)kd * s * ncb * kr * nch * kr * sizeof(float), 256);
+}
+
+/* dw: fp32 [Cout][cin_real][kd] (cin_real <= Cin: trailing padding channels of the patch rows are left out) */
+extern "C" int segk_convd_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t kd,
+                                const void* dy, int64_t ld_dy, int64_t Cout, int64_t cin_real, float* dw, int flags, void* workspace,
+                                size_t workspace_bytes, int dev, void* stream) {
+    if (int rc = check_convt("convd_wgrad(x)", dtype, x, ldx, Cin)) return rc;
+    if (int rc = check_convt("convd_wgrad(dy)", dtype, dy, ld_dy, Cout)) return rc;
+    if (int rc = check_convd("convd_wgrad", kd)) return rc;
+    SEGK_REQUIRE(dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28) && cin_real > 0 && cin_real <= Cin,
+                 SEGK_ESHAPE, "convd_wgrad: bad arguments");
+    SEGK_REQUIRE(workspace_bytes >= segk_convd_wgrad_workspace(dtype, Cin, N, D, H, W, Cout, kd), SEGK_EWORKSPACE, "convd_wgrad: workspace too small");
+    SEGK_HIP(use_device(dev));
+    const int kr = krow(dtype);
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a;
+    a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
+    a.nch0 = a.nch = (int)(round_up(Cin, kr) / kr);
+    a.N = (int)(N * D); a.H = (int)H; a.W = (int)W; a.depth = (int)D; a.nkd = (int)kd;
+    a.tiles_x = (int)((W + kTW - 1) / kTW); a.tiles_y = (int)((H + 7) / 8);
+    a.dy = (const char*)dy; a.ldy = ld_dy; a.Cout = (int)Cout; a.ncb = (int)((Cout + kr - 1) / kr);
+    a.vdy = identity_view((int)H, (int)W);
+    const int64_t ntiles = (int64_t)a.N * a.tiles_x * a.tiles_y;
+    a.splits = convd_wgrad_splits(dtype, Cin, N * D, H, W, Cout, kd);
+    a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
+    a.slab = (float*)workspace;
+    const unsigned grid = (unsigned)((int64_t)kd * a.ncb * a.nch * a.splits);
+    launch_wgrad_any(dtype, 1, a, grid, st, Cout, Cin);
+    SEGK_LAUNCH_CHECK();
+    launch_wgrad_reduce(st, (const float*)workspace, a.splits, (int64_t)a.ncb * kr, 1, a.nch * kr, (int)Cout, (int)cin_real, (int)cin_real,
+                        a.nch0 * kr, dw, (flags >> 1) & 1, 0, 0, 0, 0, 0, cin_real * kd, kd, (int)kd);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -48,6 +48,11 @@ _PROTOS = {
     "segk_conv3d_fwd": (I, [I, P, L, L, L, L, L, L, P, L, P, L, I, I, P]),
     "segk_conv3d_wgrad_workspace": (Z, [I, L, L, L, L, L, L]),
     "segk_conv3d_wgrad": (I, [I, P, L, L, L, L, L, L, P, L, L, P, I, P, Z, I, P]),
+    "segk_convd_packed_bytes": (Z, [I, L, L, L]),
+    "segk_convd_pack": (I, [P, L, L, L, I, P, P, I, P]),
+    "segk_convd_fwd": (I, [I, P, L, L, L, L, L, L, L, P, L, P, L, P, I, I, P]),
+    "segk_convd_wgrad_workspace": (Z, [I, L, L, L, L, L, L, L]),
+    "segk_convd_wgrad": (I, [I, P, L, L, L, L, L, L, L, P, L, L, L, P, I, P, Z, I, P]),
     "segk_im2col3d": (I, [I, P, L, L, L, L, L, L, P, P, P, P, L, L, I, P]),
     "segk_col2im3d": (I, [I, P, L, L, L, L, L, L, P, P, P, P, L, I, I, P]),
     "segk_maxpool3d_fwd": (I, [I, P, L, L, L, L, L, L, P, L, P, I, P]),

@@ -23,34 +23,40 @@ class Runtime3D(Runtime):
 
     # ---------------------------------------------------------------- strided stem convolutions
     def conv_patches(self, v, D, wname, kernel, stride, pad, need_dx, stats=False):
-        """Conv3d(bias=False) with an arbitrary kernel/stride on a few-channel input: patch gather + 1x1 convolution.
-        Output channels are stored rounded up to 8 (extra ones exactly zero).  -> (Var, Do)"""
+        """Conv3d(bias=False) with kernel (kd,kh,kw), stride (1,sh,sw), padding (kd/2,ph,pw) on a few-channel input,
+        factorised: the (kh,kw) window of every slice is gathered once into patch rows (kd times smaller than a full 3-D
+        gather), and a depth-only convolution on the MFMA kernel sums the kd neighbouring slices' rows.
+        Output channels are stored rounded up to 8 (extra ones exactly zero).  -> (Var, D)"""
         w = self.p[wname]
         Cout, Cin = w.shape[0], w.shape[1]
+        kd, kh, kw = kernel
         assert tuple(w.shape[2:]) == tuple(kernel)
+        if stride[0] != 1 or pad[0] != kd // 2 or kd % 2 == 0 or kd > 7:
+            raise NotImplementedError("the HIP stem convolution takes depth stride 1 with 'same' depth padding and kd in {1,3,5,7}")
         cs = (Cout + 7) // 8 * 8
-        patches, Do = ops.im2col3d(v.act, D, Cin, kernel, stride, pad)
-        K, Kp = Cin * kernel[0] * kernel[1] * kernel[2], patches.C
-        w1 = torch.zeros(cs, Kp, 1, 1, dtype=torch.float32, device=self.device)
-        w1[:Cout, :K, 0, 0] = w.detach().permute(0, 2, 3, 4, 1).reshape(Cout, K)     # tap-major, channel-minor columns
-        wf, wb = ops.conv_pack(w1, self.dtype, want_bwd=self.need_grad and need_dx)
+        k2, s2, p2 = (1, kh, kw), (1, stride[1], stride[2]), (0, pad[1], pad[2])
+        patches, _ = ops.im2col3d(v.act, D, Cin, k2, s2, p2)            # [N*D, Ho, Wo, Qp], columns (b, e, c)
+        Q, Qp = Cin * kh * kw, patches.C
+        w1 = torch.zeros(cs, Qp, kd, dtype=torch.float32, device=self.device)
+        w1[:Cout, :Q] = w.detach().permute(0, 3, 4, 1, 2).reshape(Cout, Q, kd)   # [co][(b,e,c)][a]
+        wf, wb = ops.convd_pack(w1, self.dtype, want_bwd=self.need_grad and need_dx)
         y = Var(self.new(patches.N, patches.H, patches.W, cs))
-        ops.conv_fwd(patches, wf, cs, y.act, taps=1, stat_partials=self._stat_buffer(y, stats))
+        ops.convd_fwd(patches, D, kd, wf, y.act, stat_partials=self._stat_buffer(y, stats))
 
         def bwd():
             dy = self.grad_of(y.act)
-            dw = torch.empty(cs, K, dtype=torch.float32, device=self.device)
-            ops.conv_wgrad(patches, dy, dw, taps=1, cin_real=K)
+            dw = torch.empty(cs, Q, kd, dtype=torch.float32, device=self.device)
+            ops.convd_wgrad(patches, D, kd, dy, dw, cin_real=Q)
             g = self.alloc_grad(wname, w)
-            g.copy_(dw[:Cout].view(Cout, *kernel, Cin).permute(0, 4, 1, 2, 3))
+            g.copy_(dw[:Cout].view(Cout, kh, kw, Cin, kd).permute(0, 3, 4, 1, 2))
             self._emit(wname, g)
             if need_dx:
-                dpatches = self.new(patches.N, patches.H, patches.W, Kp)
-                ops.conv_fwd(dy, wb, Kp, dpatches, taps=1)
-                ops.col2im3d(dpatches, self.grad_of(v.act), D, Cin, kernel, stride, pad, accumulate=v.ready)
+                dpatches = self.new(patches.N, patches.H, patches.W, Qp)
+                ops.convd_fwd(dy, D, kd, wb, dpatches)
+                ops.col2im3d(dpatches, self.grad_of(v.act), D, Cin, k2, s2, p2, accumulate=v.ready)
                 v.ready = True
         self.record(bwd)
-        return y, Do
+        return y, D
 
     # ---------------------------------------------------------------- 1x1x1 and 3x3x3 convolutions
     def conv1x1(self, x, wname, out=None, stats=False):

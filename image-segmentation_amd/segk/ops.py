@@ -417,6 +417,40 @@ def conv3d_wgrad(x, D, dy, dw, accumulate=False):
     return dw
 
 
+def convd_pack(w, dtype, want_fwd=True, want_bwd=True):
+    """fp32 depth-convolution weight [Cout,Cin,kd] -> (forward images, data-gradient images), one 1x1 image per depth tap."""
+    Cout, Cin, kd = w.shape
+    assert w.dtype == torch.float32 and w.is_contiguous()
+    nbytes = query("segk_convd_packed_bytes", dt(dtype), Cout, Cin, kd)
+    wf = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if want_fwd else None
+    wb = torch.empty(nbytes, dtype=torch.uint8, device=w.device) if want_bwd else None
+    dev, st = _env(w)
+    call("segk_convd_pack", w.data_ptr(), Cout, Cin, kd, dt(dtype), _p(wf), _p(wb), dev, st)
+    return wf, wb
+
+
+def convd_fwd(x, D, kd, w_packed, out, accumulate=False, stat_partials=None):
+    """out = Conv3d((kd,1,1), padding (kd/2,0,0))(x) with the forward images, or dx from dy with the data-gradient images."""
+    assert x.N % D == 0 and (out.N, out.H, out.W) == (x.N, x.H, x.W) and out.dtype == x.dtype
+    dev, st = _env(x.buf)
+    with _Timed("conv_fwd", 2.0 * x.P * x.C * out.C * kd, "128-wide" if (out.C + 31) // 32 * 32 % 128 == 0 else "narrow"):
+        call("segk_convd_fwd", dt(x.dtype), x.ptr, x.ld, x.C, x.N // D, D, x.H, x.W, kd, w_packed.data_ptr(), out.C, out.ptr, out.ld,
+             _p(stat_partials), ACCUM if accumulate else 0, dev, st)
+    return out
+
+
+def convd_wgrad(x, D, kd, dy, dw, cin_real=None, accumulate=False):
+    cin_real = cin_real or x.C
+    assert dw.dtype == torch.float32 and dw.is_contiguous() and dw.numel() == dy.C * cin_real * kd
+    dev, st = _env(x.buf)
+    d = dt(x.dtype)
+    ws = workspace(query("segk_convd_wgrad_workspace", d, x.C, x.N // D, D, x.H, x.W, dy.C, kd), x.device)
+    with _Timed("conv_wgrad", 2.0 * x.P * x.C * dy.C * kd):
+        call("segk_convd_wgrad", d, x.ptr, x.ld, x.C, x.N // D, D, x.H, x.W, kd, dy.ptr, dy.ld, dy.C, cin_real, dw.data_ptr(),
+             ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
+    return dw
+
+
 def out_extent(size, kernel, stride, pad):
     return tuple((s + 2 * p - k) // st + 1 for s, k, st, p in zip(size, kernel, stride, pad))
 

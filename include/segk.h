@@ -223,6 +223,23 @@ int segk_col2im3d(int dtype, const void* dpatches, int64_t ld_patches, int64_t C
                   const int* kernel, const int* stride, const int* pad, void* dx, int64_t ld_dx, int flags, int dev,
                   void* stream);
 
+/* Conv3d with kernel (kd, 1, 1), stride 1, padding (kd/2, 0, 0), bias=False, kd in {1,3,5,7}: the depth half of a
+ * factorised stem convolution.  The strided (kh, kw) window of every slice is gathered once into patch rows
+ * (segk_im2col3d with kernel (1,kh,kw)), and this convolution sums the kd neighbouring slices' rows: together they
+ * equal nn.Conv3d(C, Cout, (kd,kh,kw), stride (1,sh,sw), padding (kd/2,ph,pw)) with a patch tensor kd times smaller than a
+ * full 3-D gather (models/resnt.py:30; models/densenet3d.py:98-104).  w: fp32 [Cout][Cin][kd] with Cin = patch columns.
+ * segk_convd_fwd with the `wb` image on dy gives the patch gradient (-> segk_col2im3d).  stat_partials as segk_conv_fwd.
+ * dw: fp32 [Cout][cin_real][kd].  flags bit1: accumulate.                                                            */
+size_t segk_convd_packed_bytes(int dtype, int64_t Cout, int64_t Cin, int64_t kd);
+int segk_convd_pack(const float* w, int64_t Cout, int64_t Cin, int64_t kd, int dtype, void* wf, void* wb, int dev, void* stream);
+int segk_convd_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t kd,
+                   const void* w_packed, int64_t Cout, void* y, int64_t ldy, float* stat_partials, int flags, int dev,
+                   void* stream);
+size_t segk_convd_wgrad_workspace(int dtype, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t Cout, int64_t kd);
+int segk_convd_wgrad(int dtype, const void* x, int64_t ldx, int64_t Cin, int64_t N, int64_t D, int64_t H, int64_t W, int64_t kd,
+                     const void* dy, int64_t ld_dy, int64_t Cout, int64_t cin_real, float* dw, int flags, void* workspace,
+                     size_t workspace_bytes, int dev, void* stream);
+
 /* MaxPool3d(kernel 3, stride 2, padding 1): [N,D,H,W,C] -> [N,(D-1)/2+1,...]; argmax receives one byte per output
  * element (winning window position, first maximum in scan order) and drives the backward gather.
  * replaces: nn.MaxPool3d(kernel_size=3, stride=2, padding=1) (models/densenet3d.py:107-109).  flags bit1: accumulate. */

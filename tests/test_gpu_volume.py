@@ -318,3 +318,50 @@ def test_detectmid_full_size_properties():
         both = model(x)
         one = model(x[1:2])
     assert torch.equal(both[1:2], one)
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [c for c in STEMS if c[7][0] == 1], ids=lambda c: f"{c[1]}to{c[5]}_k{c[6][0]}")
+def test_stem_conv_factorised(dtype, case):
+    """Strided Conv3d = per-slice (kh,kw) patch gather + depth-only (kd,1,1) convolution on the MFMA kernel: forward,
+    patch gradient -> input gradient, and weight gradient against F.conv3d; volume faces and several volumes per batch."""
+    from segk import ops
+    N, Cin, D, H, W, Cout, k, s, p = case
+    kd, kh, kw = k
+    x = rnd((N, Cin, D, H, W), dtype, 1)
+    w = rnd((Cout, Cin) + k, dtype, 2, scale=(2.0 / (Cin * kd * kh * kw)) ** 0.5)
+    xa = to_vol(x, dtype)
+    k2, s2, p2 = (1, kh, kw), (1, s[1], s[2]), (0, p[1], p[2])
+    patches, _ = ops.im2col3d(xa, D, Cin, k2, s2, p2)
+    Q, cs = Cin * kh * kw, (Cout + 7) // 8 * 8
+    w1 = torch.zeros(cs, patches.C, kd)
+    w1[:Cout, :Q] = w.permute(0, 3, 4, 1, 2).reshape(Cout, Q, kd)
+    wf, wb = ops.convd_pack(w1.cuda(), dtype)
+    y = ops.Act.empty(patches.N, patches.H, patches.W, cs, dtype, "cuda")
+    part = ops.conv_stat_partials(y)
+    ops.convd_fwd(patches, D, kd, wf, y, stat_partials=part)
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    ref = F.conv3d(xr, wr, stride=s, padding=p)
+    report("stem_fwd", from_vol(y, N, Cout), ref.detach().float(), **TOL[dtype])
+    # the epilogue's partial sums give the batch statistics of the stored output
+    want, got = torch.empty(2 * cs, device="cuda"), torch.empty(2 * cs, device="cuda")
+    ops.norm_stats(y, 1, 1e-5, want)
+    ops.norm_stats_from_partials(part, 1, y.P, 1e-5, got)
+    report("stem_stats", got.cpu(), want.cpu(), rtol=2e-5, atol=2e-5)
+    dy = rnd(tuple(ref.shape), dtype, 3)
+    ref.backward(dy.double())
+    dya = to_vol(dy, dtype)
+    dpatches = ops.Act.empty(patches.N, patches.H, patches.W, patches.C, dtype, "cuda")
+    ops.convd_fwd(dya, D, kd, wb, dpatches)
+    dx = ops.Act.empty(N * D, H, W, 8, dtype, "cuda")
+    ops.col2im3d(dpatches, dx, D, Cin, k2, s2, p2)
+    tol = dict(TOL[dtype])
+    if dtype == torch.bfloat16:
+        tol["atol"] = 2e-2 * float(xr.grad.abs().max())
+    report("stem_dgrad", from_vol(dx, N, Cin), xr.grad.float(), **tol)
+    dw = torch.empty(cs, Q, kd, device="cuda")
+    ops.convd_wgrad(patches, D, kd, dya, dw, cin_real=Q)
+    got_w = dw[:Cout].view(Cout, kh, kw, Cin, kd).permute(0, 3, 4, 1, 2).cpu()
+    assert rel_l2(got_w, wr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+    assert float(dw[Cout:].abs().max()) == 0.0 if cs > Cout else True
