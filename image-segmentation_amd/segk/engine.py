@@ -89,10 +89,23 @@ class Runtime:
             self.zero_state.add(name)
         tensor.zero_()
 
-    def finish_forward(self):
-        if self.counters:
-            torch._foreach_add_(self.counters, 1)
-            self.counters = []
+    def finish_forward(self, owner=None):
+        """Bump the BatchNorm step counters of this forward.  With an owning module they are re-homed once as views of
+        ONE int64 tensor (kept on the module), so a step bumps all of them with a single launch."""
+        cs, self.counters = self.counters, []
+        if not cs:
+            return
+        if owner is None or len(cs) < 4:
+            torch._foreach_add_(cs, 1)
+            return
+        flat = getattr(owner, "_segk_counters", None)
+        base = flat.data_ptr() if flat is not None else 0
+        if flat is None or flat.numel() != len(cs) or any(c.data_ptr() != base + 8 * i for i, c in enumerate(cs)):
+            flat = torch.stack([c.detach() for c in cs])
+            for i, c in enumerate(cs):
+                c.data = flat[i]
+            owner._segk_counters = flat
+        flat.add_(1)
 
     def _emit(self, name, tensor):
         self.grads[name] = tensor

@@ -48,7 +48,7 @@ class _TapeFn(torch.autograd.Function):
         logits = net._emit(rt, x)
         if not plan.ready:
             plan.finalize(x.device)
-        rt.finish_forward()
+        rt.finish_forward(net)
         ctx.rt, ctx.names, ctx.hooks = rt, names, hooks
         ctx.set_materialize_grads(False)
         return logits
