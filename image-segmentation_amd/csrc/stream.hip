@@ -823,6 +823,39 @@ __global__ __launch_bounds__(kThreads) void copy_slice_kernel(const T* __restric
     }
 }
 
+// 2x2 blocks of pixels <-> channels: wide[n, oh, ow, (b*2 + e)*C + c] = x[n, 2*oh + b, 2*ow + e, c].
+// With the weight of a Conv2d(kernel 2, stride 2) read as [Cout][(b, e, c)] the strided convolution is a 1x1 convolution
+// over `wide`; `to_wide` = 0 runs the permutation backwards (its adjoint: the data gradient), optionally adding.
+template <typename T>
+__global__ __launch_bounds__(kThreads) void block2_kernel(T* __restrict__ x, int64_t ldx, T* __restrict__ wide, int64_t ldw, int64_t N,
+                                                          int Ho, int Wo, int C, int to_wide, int accumulate) {
+    const int cv = C / 8;
+    const int64_t items = N * Ho * Wo * 4 * cv;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int v = (int)(i % cv);
+        int64_t p = i / cv;
+        const int tap = (int)(p & 3); p >>= 2;                      // p: output pixel (n, oh, ow)
+        const int ow = (int)(p % Wo);
+        const int64_t r = p / Wo;                                   // n*Ho + oh
+        T* xs = x + ((2 * r + (tap >> 1)) * (2 * Wo) + 2 * ow + (tap & 1)) * ldx + v * 8;
+        T* ws = wide + p * ldw + tap * C + v * 8;
+        float a[8];
+        if (to_wide) {
+            Elem<T>::load8(xs, a);
+            Elem<T>::store8(ws, a);
+        } else {
+            Elem<T>::load8(ws, a);
+            if (accumulate) {
+                float b[8];
+                Elem<T>::load8(xs, b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] += b[j];
+            }
+            Elem<T>::store8(xs, a);
+        }
+    }
+}
+
 // dx = dy where the saved activation y is positive, else 0 (backward of a ReLU that follows a layer without norm)
 template <typename T>
 __global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy, const T* __restrict__ y,
@@ -885,7 +918,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd_kernel(const T* __restrict_
                                                             int64_t ld_dx, int relu_mask, float* __restrict__ ws) {
     __shared__ float red[kThreads / 64][8][COUT * 8 + 1];   // [wave][channel vector][c*8+j], padded against bank conflicts
     __shared__ float dbs[kThreads / 64][COUT];
-    const int cv = Cin / 8;                      // 4 or 8 (Cin 32 / 64): divides 64
+    const int cv = Cin / 8;                      // 1, 2, 4 or 8 (Cin 8 .. 64): divides 64
     const int v = threadIdx.x % cv;
     const int64_t P = N * HW, items = P * cv;
     float wr[COUT][8], acc[COUT][8], db[COUT];
@@ -1344,6 +1377,20 @@ extern "C" int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void*
     return SEGK_OK;
 }
 
+extern "C" int segk_block2(int dtype, void* x, int64_t ldx, void* wide, int64_t ld_wide, int64_t N, int64_t H, int64_t W, int64_t C,
+                           int flags, int dev, void* stream) {
+    SEGK_CHECK_ACT("block2(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("block2(wide)", wide, ld_wide, 4 * C, dtype);
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && H < (1 << 20) && W < (1 << 20), SEGK_ESHAPE,
+                 "block2: H and W must be even (got %lldx%lld)", (long long)H, (long long)W);
+    SEGK_HIP(use_device(dev));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((block2_kernel<T>), dim3(grid_for(N * H * W * (C / 8))), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (T*)x, ldx, (T*)wide, ld_wide, N, (int)(H / 2), (int)(W / 2), (int)C,
+                                                     (flags & 1) ? 0 : 1, (flags >> 1) & 1));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
 extern "C" int segk_head1x1_fwd(int dtype, const void* x, int64_t ld, int64_t Cin, int64_t N, int64_t HW, const float* w,
                                 const float* bias, int64_t Cout, float* logits, int dev, void* stream) {
     SEGK_CHECK_ACT("head1x1_fwd", x, ld, Cin, dtype);
@@ -1386,7 +1433,7 @@ extern "C" int segk_head1x1_bwd(int dtype, const void* x, int64_t ld, int64_t Ci
     SEGK_CHECK_ACT("head1x1_bwd(x)", x, ld, Cin, dtype);
     SEGK_CHECK_ACT("head1x1_bwd(dx)", dx, ld_dx, Cin, dtype);
     SEGK_REQUIRE(w && dlogits && dw && workspace && N > 0 && HW > 0, SEGK_EINVAL, "head1x1_bwd: bad arguments");
-    SEGK_REQUIRE(Cin == 32 || Cin == 64, SEGK_ESHAPE, "head1x1_bwd: Cin must be 32 or 64 (got %lld)", (long long)Cin);
+    SEGK_REQUIRE(Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, SEGK_ESHAPE, "head1x1_bwd: Cin must be 8, 16, 32 or 64 (got %lld)", (long long)Cin);
     SEGK_REQUIRE(workspace_bytes >= segk_head1x1_bwd_workspace(Cin, Cout, N, HW), SEGK_EWORKSPACE, "head1x1_bwd: workspace too small");
     SEGK_HIP(use_device(dev));
     hipStream_t st = (hipStream_t)stream;

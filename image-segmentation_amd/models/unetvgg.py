@@ -1,7 +1,8 @@
 """U-Net with a VGG16-BN encoder, MI355X-native.
 
 Same constructor signatures, attribute names and state_dict layout as the reference classes
-(/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213),
+(/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213,
+make_encoder_block :268-323, UNetSimple :651-728),
 so checkpoints and callers are interchangeable.  The module tree is made of ordinary torch.nn layers
 that only hold the parameters (and serve CPU tensors); for CUDA tensors `forward` hands the
 parameters to the segk tape (segk/engine.py), which launches the HIP kernels: implicit-GEMM
@@ -163,3 +164,122 @@ class UNetVggInOut(_UNetVggBase):
             raise RuntimeError("pretrained VGG16-BN weights need a download, which is unavailable here")
         self.patch_train = patch_train
         self._build(out_classes, False, in_classes)
+
+
+class EncoderBlock(nn.Sequential):
+    """Contraction unit of the plain U-Nets (reference make_encoder_block :268-323): a down-sampling layer, then two or
+    three conv3x3(bias=False) + InstanceNorm2d + ReLU groups; child indices as in the reference."""
+
+    def __init__(self, in_channels, middle_channels, out_channels, convs3=True, middle_channels2=None, max_pool=False,
+                 no_dsam=False, if_interpolate=False, downsc=2):
+        if if_interpolate:
+            down, kind = nn.Upsample(scale_factor=downsc, mode="bilinear", align_corners=False), "interpolate"
+        elif no_dsam:
+            down, kind = nn.Conv2d(in_channels, in_channels, kernel_size=3, padding=1), "conv3"
+        elif max_pool:
+            down, kind = nn.MaxPool2d(kernel_size=2, stride=2), "pool"
+        else:
+            down, kind = nn.Conv2d(in_channels, in_channels, kernel_size=2, stride=2), "conv2"
+        widths = [middle_channels] + ([middle_channels2] if convs3 else []) + [out_channels]
+        layers, c = [down], in_channels
+        for width in widths:
+            layers += [nn.Conv2d(c, width, 3, padding=1, bias=False), nn.InstanceNorm2d(width), nn.ReLU(inplace=True)]
+            c = width
+        super().__init__(*layers)
+        self.kind, self.groups = kind, len(widths)
+
+    def emit(self, rt, prefix, x, out=None):
+        """Append this block to a segk tape; the last group writes into `out` (a slice of a concat buffer)."""
+        if self.kind == "conv2":
+            h = rt.conv_down2(x, prefix + "0.weight", prefix + "0.bias")
+        elif self.kind == "conv3":
+            h = rt.conv(x, prefix + "0.weight", prefix + "0.bias")
+        elif self.kind == "pool":
+            h = rt.pool(x)
+        else:
+            raise NotImplementedError("bilinear re-scaling of the encoder input has no HIP kernel (scale factor 2 up-sampling only)")
+        for j in range(self.groups):
+            y = rt.conv(h, f"{prefix}{1 + 3 * j}.weight", stats="instance")
+            h = rt.in_up_relu(y, upsample=False, out=out if j == self.groups - 1 else None)
+        return h
+
+
+def make_encoder_block(in_channels, middle_channels, out_channels, convs3=True, middle_channels2=None, max_pool=False,
+                       no_dsam=False, if_interpolate=False, downsc=2):
+    return EncoderBlock(in_channels, middle_channels, out_channels, convs3=convs3, middle_channels2=middle_channels2,
+                        max_pool=max_pool, no_dsam=no_dsam, if_interpolate=if_interpolate, downsc=downsc)
+
+
+class UNetSimple(SegkNet):
+    """Four-level U-Net with InstanceNorm and learned stride-2 down-sampling (reference :651-728); `pretrained` is
+    accepted and unused, as there."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1, channelscale=64, multiout=False,
+                 noupdownsam=False):
+        super().__init__()
+        cs = channelscale
+        self.multiout, self.patch_train, self.channelscale, self.noupdownsam = multiout, patch_train, cs, noupdownsam
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(in_classes, cs, 3, padding=1, bias=False), nn.InstanceNorm2d(cs), nn.ReLU(inplace=True),
+            nn.Conv2d(cs, cs, 3, padding=1, bias=False), nn.InstanceNorm2d(cs), nn.ReLU(inplace=True))
+        self.conv2 = make_encoder_block(cs, 2 * cs, 2 * cs, convs3=False, no_dsam=noupdownsam)
+        self.conv3 = make_encoder_block(2 * cs, 4 * cs, 4 * cs, middle_channels2=4 * cs, no_dsam=noupdownsam)
+        self.conv4 = make_encoder_block(4 * cs, 8 * cs, 8 * cs, middle_channels2=8 * cs, no_dsam=noupdownsam)
+        # the two InstanceNorm2d widths are the reference's literals; without affine parameters the width is unused
+        self.conv5 = nn.Sequential(
+            nn.Conv2d(8 * cs, 8 * cs, kernel_size=3, padding=1), nn.InstanceNorm2d(512),
+            nn.Conv2d(8 * cs, 8 * cs, kernel_size=3, padding=1), nn.ReLU(inplace=True),
+            nn.Conv2d(8 * cs, 8 * cs, kernel_size=3, padding=1), nn.InstanceNorm2d(4 * cs), nn.ReLU(inplace=True))
+        self.dec4 = make_decoder_block(16 * cs, 8 * cs, 4 * cs, noupsam=noupdownsam)
+        self.dec3 = make_decoder_block(8 * cs, 4 * cs, cs, noupsam=noupdownsam)
+        self.dec2 = make_decoder_block(3 * cs, 2 * cs, cs // 2, noupsam=noupdownsam)
+        self.dec1 = nn.Sequential(nn.Conv2d(int(1.5 * cs), cs // 2, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(cs // 2, out_classes, kernel_size=1)
+
+    def _forward_host(self, x):
+        conv1 = self.conv1(x)
+        conv2 = self.conv2(conv1)
+        conv3 = self.conv3(conv2)
+        conv4 = self.conv4(conv3)
+        conv5 = self.conv5(conv4)
+        dec4 = self.dec4(torch.cat([conv5, conv4], 1))
+        dec3 = self.dec3(torch.cat([dec4, conv3], 1))
+        dec2 = self.dec2(torch.cat([dec3, conv2], 1))
+        dec1 = self.dec1(torch.cat([dec2, conv1], 1))
+        if self.multiout:
+            return self.final(dec1), [dec1, dec2, dec3, dec4]
+        return self.final(dec1)
+
+    def _emit(self, rt, x):
+        if self.multiout:
+            raise NotImplementedError("the HIP tape returns the logits only; construct with multiout=False")
+        N, _, H, W = x.shape
+        cs, down = self.channelscale, not self.noupdownsam
+        if cs % 16:
+            raise NotImplementedError("channelscale must be a multiple of 16 (8-channel storage groups)")
+        if down and (H % 8 or W % 8):
+            raise RuntimeError(f"UNetSimple needs H and W divisible by 8 (three stride-2 convolutions), got {H}x{W}")
+
+        def level(k, C):
+            return rt.new(N, H >> k if down else H, W >> k if down else W, C).buf
+        # concat buffers of reference :720-723, written in place
+        cat1, cat2 = level(0, cs // 2 + cs), level(1, cs + 2 * cs)            # [dec2 | conv1], [dec3 | conv2]
+        cat3, cat4 = level(2, 4 * cs + 4 * cs), level(3, 8 * cs + 8 * cs)     # [dec4 | conv3], [conv5 | conv4]
+        y = rt.conv_first(x, "conv1.0.weight", None, stats="instance")
+        h = rt.in_up_relu(y, upsample=False)
+        y = rt.conv(h, "conv1.3.weight", stats="instance")
+        c1 = rt.in_up_relu(y, upsample=False, out=Act(cat1, cs // 2, cs))
+        c2 = self.conv2.emit(rt, "conv2.", c1, out=Act(cat2, cs, 2 * cs))
+        c3 = self.conv3.emit(rt, "conv3.", c2, out=Act(cat3, 4 * cs, 4 * cs))
+        c4 = self.conv4.emit(rt, "conv4.", c3, out=Act(cat4, 8 * cs, 8 * cs))
+        # a bias in front of an InstanceNorm cancels: its gradient is exactly zero
+        y = rt.conv(c4, "conv5.0.weight", "conv5.0.bias", stats="instance", bias_grad_zero=True)
+        h = rt.in_up_relu(y, upsample=False, relu=False)
+        h = rt.conv(h, "conv5.2.weight", "conv5.2.bias", relu=True)
+        y = rt.conv(h, "conv5.4.weight", "conv5.4.bias", stats="instance", bias_grad_zero=True)
+        c5 = rt.in_up_relu(y, upsample=False, out=Act(cat4, 0, 8 * cs))
+        d4 = self.dec4.emit(rt, "dec4.", [c5, c4], out=Act(cat3, 0, 4 * cs))
+        d3 = self.dec3.emit(rt, "dec3.", [d4, c3], out=Act(cat2, 0, cs))
+        d2 = self.dec2.emit(rt, "dec2.", [d3, c2], out=Act(cat1, 0, cs // 2))
+        e = rt.conv([d2, c1], "dec1.0.weight", "dec1.0.bias", relu=True)
+        return rt.head(e, "final.weight", "final.bias")

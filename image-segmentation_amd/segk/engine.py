@@ -204,7 +204,8 @@ class Runtime:
         wf, _ = ops.conv_pack(w1, self.dtype, want_bwd=False)
         N, _, H, W = x.shape
         y = Var(self.new(N, H, W, cs))
-        ops.conv_fwd(patches, wf, cs, y.act, taps=1, bias=self._bias(bname, cs), stat_partials=self._stat_buffer(y, stats))
+        ops.conv_fwd(patches, wf, cs, y.act, taps=1, bias=self._bias(bname, cs),
+                     stat_partials=self._stat_buffer(y, stats, norm_groups=N if stats == "instance" else None))
 
         def bwd():
             dy = self.grad_of(y.act)
@@ -318,6 +319,41 @@ class Runtime:
         for m in mem0 + mem1:
             m.ready = True
 
+    def conv_down2(self, x, wname, bname=None):
+        """Conv2d(kernel_size=2, stride=2) (models/unetvgg.py:305): the 2x2 pixel blocks are gathered into channels and
+        a 1x1 convolution on the matrix cores does the arithmetic."""
+        assert not x.relu_fused, "the block gather cannot consume a tensor whose ReLU backward is deferred"
+        w = self.p[wname]
+        Cout, Cin = w.shape[0], w.shape[1]
+        a = x.act
+        assert a.C == Cin and tuple(w.shape[2:]) == (2, 2)
+        wide = self.new(a.N, a.H // 2, a.W // 2, 4 * Cin)
+        ops.block2(a, wide)
+        w1 = w.detach().permute(0, 2, 3, 1).reshape(Cout, 4 * Cin, 1, 1).contiguous()      # [co][(b, e, c)]
+        wf, wb = ops.conv_pack(w1, self.dtype, want_fwd=True, want_bwd=self.need_grad)
+        y = Var(self.new(a.N, a.H // 2, a.W // 2, Cout))
+        ops.conv_fwd(wide, wf, Cout, y.act, taps=1, bias=self._bias(bname))
+
+        def bwd():
+            dy = self.grad_of(y.act)
+            dw = torch.empty(Cout, 4 * Cin, dtype=torch.float32, device=self.device)
+            ops.conv_wgrad(wide, dy, dw, taps=1)
+            g = self.alloc_grad(wname, w)
+            g.copy_(dw.view(Cout, 2, 2, Cin).permute(0, 3, 1, 2))
+            self._emit(wname, g)
+            if bname is not None:
+                db = self.alloc_grad(bname, self.p[bname])
+                if self.zero_state is not None:
+                    self.zero_state.discard(bname)
+                ops.colsum(dy, db)
+                self._emit(bname, db)
+            dwide = self.new(a.N, a.H // 2, a.W // 2, 4 * Cin)
+            ops.conv_fwd(dy, wb, 4 * Cin, dwide, taps=1)
+            ops.block2(self.grad_of(a), dwide, backward=True, accumulate=x.ready)
+            x.ready = True
+        self.record(bwd)
+        return y
+
     def conv_transpose_relu(self, h, wname, bname, out=None):
         """ConvTranspose2d(4, stride 2, padding 1) + ReLU (models/unetvgg.py:31-32,41)."""
         w = self.p[wname]
@@ -388,8 +424,10 @@ class Runtime:
         self.record(bwd)
         return p
 
-    def in_up_relu(self, y, out=None, eps=1e-5, upsample=True):
-        """InstanceNorm2d(affine=False) -> bilinear x2 (align_corners=False) -> ReLU, one pass over the output."""
+    def in_up_relu(self, y, out=None, eps=1e-5, upsample=True, relu=True):
+        """InstanceNorm2d(affine=False) -> bilinear x2 (align_corners=False) -> ReLU, one pass over the output.
+        upsample=False: InstanceNorm2d (-> ReLU unless relu=False) at the input's size."""
+        assert relu or not upsample
         x = y.act
         stats = torch.empty(2 * x.N * x.C, dtype=torch.float32, device=self.device)
         self._norm_stats(y, x.N, eps, stats)
@@ -399,7 +437,7 @@ class Runtime:
             ops.upsample_fwd(x, u.act, stats=stats, relu=True, align=False)
         else:
             u = Var(out or self.new(x.N, x.H, x.W, x.C))
-            ops.norm_apply(x, x.N, stats, None, None, True, u.act)
+            ops.norm_apply(x, x.N, stats, None, None, relu, u.act)
 
         def bwd():
             du = self.grad_of(u.act)
@@ -409,7 +447,7 @@ class Runtime:
                 ops.upsample_bwd(du, None, dxh, relu=False, align=False)
                 ops.norm_bwd(dxh, x, x.N, stats, None, None, False, dy)
             else:
-                ops.norm_bwd(du, x, x.N, stats, None, None, True, dy)
+                ops.norm_bwd(du, x, x.N, stats, None, None, relu, dy)
             y.ready = True
         self.record(bwd)
         return u

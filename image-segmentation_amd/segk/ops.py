@@ -451,6 +451,15 @@ def convd_wgrad(x, D, kd, dy, dw, cin_real=None, accumulate=False):
     return dw
 
 
+def block2(x, wide, backward=False, accumulate=False):
+    """[N,H,W,C] <-> [N,H/2,W/2,4C] (2x2 pixel blocks as channels, tap-major); backward: x (+)= from wide."""
+    assert wide.C == 4 * x.C and wide.N == x.N and 2 * wide.H == x.H and 2 * wide.W == x.W
+    dev, st = _env(x.buf)
+    call("segk_block2", dt(x.dtype), x.ptr, x.ld, wide.ptr, wide.ld, x.N, x.H, x.W, x.C,
+         (1 if backward else 0) | (ACCUM if accumulate and backward else 0), dev, st)
+    return x if backward else wide
+
+
 def out_extent(size, kernel, stride, pad):
     return tuple((s + 2 * p - k) // st + 1 for s, k, st, p in zip(size, kernel, stride, pad))
 

@@ -364,6 +364,14 @@ int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int64_t C, floa
 int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t P,
                     int64_t C, int flags, int dev, void* stream);
 
+/* 2x2 pixel blocks <-> channels: wide[n,oh,ow,(b*2+e)*C + c] = x[n,2*oh+b,2*ow+e,c] ([N,H,W,C] -> [N,H/2,W/2,4C]).
+ * With the weight read as [Cout][(b,e,c)] a Conv2d(kernel_size=2, stride=2) becomes a 1x1 convolution over
+ * `wide` (segk_conv_fwd with taps = 1).  flags bit0: run backwards (x from wide: the data gradient);
+ * bit1 (with bit0): x += .
+ * replaces: the strided down-sampling Conv2d of make_encoder_block, models/unetvgg.py:305.          */
+int segk_block2(int dtype, void* x, int64_t ldx, void* wide, int64_t ld_wide, int64_t N, int64_t H, int64_t W,
+                int64_t C, int flags, int dev, void* stream);
+
 /* Fused multi-tensor Adam step (torch.optim.Adam defaults; perlosstrain/naive_train.py:397-398,
  * pl_utils/pl_mod.py:109-110).  One flat fp32 parameter / gradient / moment buffer.                */
 int segk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -151,44 +151,50 @@ def run_step(model, x, t, losses):
     return logits.detach(), loss.detach()
 
 
+def _model_fixture(name, mk_ref, mk_or, in_ch, n_cls, out, keys, pin, dice_ref, focal_ref):
+    """One training step of the reference network `mk_ref()` and of its oracle restatement `mk_or()` on the same
+    hash-initialised weights and synthetic batch: bitwise comparison into `pin`, reference outputs into `out`."""
+    x, t = RM.synthetic_batch(2, 64, n_cls, in_ch=in_ch, tag=f"model:{name}")
+    m_ref = RM.hash_init_(mk_ref())
+    m_or = RM.hash_init_(mk_or())
+    assert list(m_ref.state_dict().keys()) == list(m_or.state_dict().keys()), name
+    for (ka, va), (kb, vb) in zip(m_ref.state_dict().items(), m_or.state_dict().items()):
+        assert va.shape == vb.shape and torch.equal(va, vb), (name, ka)
+    keys[name] = {k: list(v.shape) for k, v in m_ref.state_dict().items()}
+    la, lossa = run_step(m_ref, x, t, [dice_ref.dice_loss_sq, focal_ref.focal_loss_with_logits])
+    lb, lossb = run_step(m_or, x, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
+    same = bits_equal(la, lb) and bits_equal(lossa, lossb)
+    for (ka, pa), (_, pb) in zip(m_ref.named_parameters(), m_or.named_parameters()):
+        same = same and bits_equal(pa.grad, pb.grad)
+    for (ka, ba), (_, bb) in zip(m_ref.named_buffers(), m_or.named_buffers()):
+        same = same and bits_equal(ba, bb)
+    pin[f"model/{name}"] = bool(same)
+    out[f"{name}/logits"] = la.numpy()
+    out[f"{name}/loss"] = lossa.numpy()
+    out[f"{name}/mask"] = la.argmax(1).to(torch.uint8).numpy()
+    top2 = la.topk(2, dim=1).values
+    out[f"{name}/near_tie_1e-3"] = np.int64(((top2[:, 0] - top2[:, 1]) < 1e-3).sum().item())
+    for k, p in m_ref.named_parameters():
+        g = p.grad.flatten()
+        out[f"{name}/grad_norm/{k}"] = np.float64(g.double().norm().item())
+        out[f"{name}/grad_head/{k}"] = g[:16].numpy().copy()
+    for k, b in m_ref.named_buffers():
+        if not k.endswith("num_batches_tracked"):
+            out[f"{name}/buf/{k}"] = b.numpy().copy()
+    # eval-mode logits after the step (running statistics path)
+    m_ref.eval()
+    with torch.no_grad():
+        le = m_ref(x)
+    out[f"{name}/eval_logits_sub"] = le[..., ::4, ::4].contiguous().numpy()
+    out[f"{name}/eval_mask"] = le.argmax(1).to(torch.uint8).numpy()
+
+
 def golden_models(ref, pin):
     dice_ref, focal_ref = ref["loss.dice"], ref["loss.focal"]
     out, keys = {}, {}
     for name, mk_ref, mk_or, in_ch in model_cases(ref):
         n_cls = 3 if name.endswith("c3") else 4
-        x, t = RM.synthetic_batch(2, 64, n_cls, in_ch=in_ch, tag=f"model:{name}")
-        m_ref = RM.hash_init_(mk_ref())
-        m_or = RM.hash_init_(mk_or())
-        assert list(m_ref.state_dict().keys()) == list(m_or.state_dict().keys()), name
-        for (ka, va), (kb, vb) in zip(m_ref.state_dict().items(), m_or.state_dict().items()):
-            assert va.shape == vb.shape and torch.equal(va, vb), (name, ka)
-        keys[name] = {k: list(v.shape) for k, v in m_ref.state_dict().items()}
-        la, lossa = run_step(m_ref, x, t, [dice_ref.dice_loss_sq, focal_ref.focal_loss_with_logits])
-        lb, lossb = run_step(m_or, x, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
-        same = bits_equal(la, lb) and bits_equal(lossa, lossb)
-        for (ka, pa), (_, pb) in zip(m_ref.named_parameters(), m_or.named_parameters()):
-            same = same and bits_equal(pa.grad, pb.grad)
-        for (ka, ba), (_, bb) in zip(m_ref.named_buffers(), m_or.named_buffers()):
-            same = same and bits_equal(ba, bb)
-        pin[f"model/{name}"] = bool(same)
-        out[f"{name}/logits"] = la.numpy()
-        out[f"{name}/loss"] = lossa.numpy()
-        out[f"{name}/mask"] = la.argmax(1).to(torch.uint8).numpy()
-        top2 = la.topk(2, dim=1).values
-        out[f"{name}/near_tie_1e-3"] = np.int64(((top2[:, 0] - top2[:, 1]) < 1e-3).sum().item())
-        for k, p in m_ref.named_parameters():
-            g = p.grad.flatten()
-            out[f"{name}/grad_norm/{k}"] = np.float64(g.double().norm().item())
-            out[f"{name}/grad_head/{k}"] = g[:16].numpy().copy()
-        for k, b in m_ref.named_buffers():
-            if not k.endswith("num_batches_tracked"):
-                out[f"{name}/buf/{k}"] = b.numpy().copy()
-        # eval-mode logits after the step (running statistics path)
-        m_ref.eval()
-        with torch.no_grad():
-            le = m_ref(x)
-        out[f"{name}/eval_logits_sub"] = le[..., ::4, ::4].contiguous().numpy()
-        out[f"{name}/eval_mask"] = le.argmax(1).to(torch.uint8).numpy()
+        _model_fixture(name, mk_ref, mk_or, in_ch, n_cls, out, keys, pin, dice_ref, focal_ref)
     # one full-size slice: UNetVgg 384x384, N=1, C=4
     uv = ref["models.unetvgg"]
     x, t = RM.synthetic_batch(1, 384, 4, in_ch=3, tag="model:unetvgg384")
@@ -209,6 +215,34 @@ def golden_models(ref, pin):
     np.savez_compressed(os.path.join(GOLD, "models.npz"), **out)
     with open(os.path.join(GOLD, "state_dict_keys.json"), "w") as f:
         json.dump(keys, f, indent=0)
+
+
+# ------------------------------------------------------------------------------------ further U-Net variants
+def variant_cases(ref):
+    uv = ref["models.unetvgg"]
+    return [
+        ("unetsimple_c4", lambda: uv.UNetSimple(out_classes=4, in_classes=1), lambda: RM.RefUNetSimple(out_classes=4, in_classes=1), 1),
+        ("unetsimple_cs32_c3", lambda: uv.UNetSimple(out_classes=3, in_classes=1, channelscale=32),
+         lambda: RM.RefUNetSimple(out_classes=3, in_classes=1, channelscale=32), 1),
+        ("unetsimple_flat_cs16_c4", lambda: uv.UNetSimple(out_classes=4, in_classes=1, channelscale=16, noupdownsam=True),
+         lambda: RM.RefUNetSimple(out_classes=4, in_classes=1, channelscale=16, noupdownsam=True), 1),
+    ]
+
+
+def golden_variants(ref, pin):
+    """UNetSimple (models/unetvgg.py:651-728): default width, half width, and the variant without re-scaling."""
+    import warnings
+    warnings.filterwarnings("ignore", message=".*num_features.*")
+    dice_ref, focal_ref = ref["loss.dice"], ref["loss.focal"]
+    out, keys = {}, {}
+    for name, mk_ref, mk_or, in_ch in variant_cases(ref):
+        _model_fixture(name, mk_ref, mk_or, in_ch, 3 if name.endswith("c3") else 4, out, keys, pin, dice_ref, focal_ref)
+    np.savez_compressed(os.path.join(GOLD, "variants.npz"), **out)
+    kf = os.path.join(GOLD, "state_dict_keys.json")
+    allkeys = json.load(open(kf)) if os.path.exists(kf) else {}
+    allkeys.update(keys)
+    with open(kf, "w") as f:
+        json.dump(allkeys, f, indent=0)
 
 
 # ------------------------------------------------------------------------------------ 3-D classifier
@@ -269,7 +303,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
     pin = {}
-    partial = [a for a in ("--volumes-only", "--aux-losses-only") if a in sys.argv]
+    partial = [a for a in ("--volumes-only", "--aux-losses-only", "--variants-only") if a in sys.argv]
     if partial:                           # refresh one fixture file without regenerating the others
         pf = os.path.join(GOLD, "oracle_pin.json")
         pin = json.load(open(pf))["checks"] if os.path.exists(pf) else {}
@@ -277,10 +311,13 @@ def main():
             golden_volumes(ref, pin)
         if "--aux-losses-only" in partial:
             golden_aux_losses(ref, pin)
+        if "--variants-only" in partial:
+            golden_variants(ref, pin)
     else:
         golden_losses(ref, pin)
         golden_aux_losses(ref, pin)
         golden_models(ref, pin)
+        golden_variants(ref, pin)
         golden_volumes(ref, pin)
     verdict = {"torch": torch.__version__, "numpy": np.__version__, "all_bitwise_equal": all(pin.values()), "checks": pin}
     with open(os.path.join(GOLD, "oracle_pin.json"), "w") as f:

@@ -4,6 +4,7 @@ Plain `torch.nn` restatement of the two graded networks with the reference's sta
 
 * VGG16-BN encoder + five-stage decoder -- /root/reference/models/unetvgg.py:6-41 (decoder block),
   :52-105 (UNetVgg), :158-213 (UNetVggInOut)
+* plain InstanceNorm U-Net              -- /root/reference/models/unetvgg.py:268-323 (encoder block), :651-728 (UNetSimple)
 * nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
 * 3-D DenseNet-BC classifier + DetectMid -- /root/reference/models/densenet3d.py:10-159, 162-186;
                                            /root/reference/models/resnt.py:8-45
@@ -76,6 +77,46 @@ class RefUNetVgg(nn.Module):
         for k in range(5, 0, -1):
             x = getattr(self, f"dec{k}")(torch.cat([x, skips[k - 1]], 1))
         return self.final(x)
+
+
+def encoder_block(c_in, c_mid, c_out, convs3=True, c_mid2=None, no_dsam=False):
+    """unetvgg.py:268-323 with max_pool=False, if_interpolate=False (the settings UNetSimple uses)."""
+    down = nn.Conv2d(c_in, c_in, 3, padding=1) if no_dsam else nn.Conv2d(c_in, c_in, kernel_size=2, stride=2)
+    mods, c = [down], c_in
+    for wdt in [c_mid] + ([c_mid2] if convs3 else []) + [c_out]:
+        mods += [nn.Conv2d(c, wdt, 3, padding=1, bias=False), nn.InstanceNorm2d(wdt), nn.ReLU(inplace=True)]
+        c = wdt
+    return nn.Sequential(*mods)
+
+
+class RefUNetSimple(nn.Module):
+    def __init__(self, out_classes=3, in_classes=1, channelscale=64, noupdownsam=False):
+        super().__init__()
+        cs, nd = channelscale, noupdownsam
+        self.conv1 = nn.Sequential(nn.Conv2d(in_classes, cs, 3, padding=1, bias=False), nn.InstanceNorm2d(cs), nn.ReLU(inplace=True),
+                                   nn.Conv2d(cs, cs, 3, padding=1, bias=False), nn.InstanceNorm2d(cs), nn.ReLU(inplace=True))
+        self.conv2 = encoder_block(cs, 2 * cs, 2 * cs, convs3=False, no_dsam=nd)
+        self.conv3 = encoder_block(2 * cs, 4 * cs, 4 * cs, c_mid2=4 * cs, no_dsam=nd)
+        self.conv4 = encoder_block(4 * cs, 8 * cs, 8 * cs, c_mid2=8 * cs, no_dsam=nd)
+        self.conv5 = nn.Sequential(nn.Conv2d(8 * cs, 8 * cs, 3, padding=1), nn.InstanceNorm2d(8 * cs),
+                                   nn.Conv2d(8 * cs, 8 * cs, 3, padding=1), nn.ReLU(inplace=True),
+                                   nn.Conv2d(8 * cs, 8 * cs, 3, padding=1), nn.InstanceNorm2d(8 * cs), nn.ReLU(inplace=True))
+        self.dec4 = decoder_block(16 * cs, 8 * cs, 4 * cs, noupsam=nd)
+        self.dec3 = decoder_block(8 * cs, 4 * cs, cs, noupsam=nd)
+        self.dec2 = decoder_block(3 * cs, 2 * cs, cs // 2, noupsam=nd)
+        self.dec1 = nn.Sequential(nn.Conv2d(cs + cs // 2, cs // 2, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(cs // 2, out_classes, 1)
+
+    def forward(self, x):
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c4 = self.conv4(c3)
+        c5 = self.conv5(c4)
+        d = self.dec4(torch.cat([c5, c4], 1))
+        d = self.dec3(torch.cat([d, c3], 1))
+        d = self.dec2(torch.cat([d, c2], 1))
+        return self.final(self.dec1(torch.cat([d, c1], 1)))
 
 
 class RefDoubleConv(nn.Module):

@@ -28,4 +28,14 @@ def pytest_collection_modifyitems(config, items):
 def golden():
     import numpy as np
     d = os.path.join(ROOT, "tests", "golden")
-    return {"losses": np.load(os.path.join(d, "losses.npz")), "models": np.load(os.path.join(d, "models.npz"))}
+    class Merged:
+        """Read-only union of several .npz fixture files."""
+        def __init__(self, *files):
+            self.files = [np.load(os.path.join(d, f)) for f in files]
+
+        def __getitem__(self, key):
+            for f in self.files:
+                if key in f.files:
+                    return f[key]
+            raise KeyError(key)
+    return {"losses": np.load(os.path.join(d, "losses.npz")), "models": Merged("models.npz", "variants.npz")}

@@ -447,3 +447,37 @@ def test_conv_epilogue_statistics(dtype, case):
         if run:
             report("running_mean", rm1.cpu(), rm0.cpu(), rtol=1e-5, atol=1e-6)
             report("running_var", rv1.cpu(), rv0.cpu(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_strided_2x2_convolution(dtype):
+    """Conv2d(kernel_size=2, stride=2) (models/unetvgg.py:305) = 2x2 block gather + 1x1 convolution; forward, weight,
+    bias and data gradients against torch, the data gradient also accumulating into a slice of a wider buffer."""
+    from segk import ops
+    from segk.engine import Runtime, Var
+    N, C, Co, H, W = 2, 24, 16, 12, 20
+    x, w, b = rnd((N, C, H, W), dtype, 81), rnd((Co, C, 2, 2), torch.float32, 82, 0.2), rnd((Co,), torch.float32, 83)
+    dy = rnd((N, Co, H // 2, W // 2), dtype, 84)
+    xa = ops.Act(torch.zeros(N, H, W, 64, device="cuda", dtype=dtype), 8, C)
+    xa.nchw().copy_(x)
+    wide = ops.block2(xa, ops.Act.empty(N, H // 2, W // 2, 4 * C, dtype, "cuda"))
+    want = x.view(N, C, H // 2, 2, W // 2, 2).permute(0, 2, 4, 3, 5, 1).reshape(N, H // 2, W // 2, 4 * C)
+    assert torch.equal(wide.buf.float().cpu(), want)                      # a permutation: bit-exact
+    back = ops.Act(torch.ones(N, H, W, 64, device="cuda", dtype=dtype), 8, C)
+    ops.block2(back, wide, backward=True, accumulate=True)
+    assert torch.equal(from_act(back), (x + 1).to(dtype).float()) and float(back.buf[..., :8].sub(1).abs().max()) == 0
+    # through the tape
+    wp, bp = w.cuda().requires_grad_(True), b.cuda().requires_grad_(True)
+    rt = Runtime({"w": wp, "b": bp}, {}, dtype, torch.device("cuda"), True, True)
+    v = Var(xa)
+    y = rt.conv_down2(v, "w", "b")
+    xd, wd, bd = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(xd, wd, bd, stride=2)
+    ref.backward(dy)
+    report("down2_y", from_act(y.act), ref.detach(), **TOL[dtype])
+    rt.grad_of(y.act).nchw().copy_(dy)
+    rt.backward_keep()
+    report("down2_dx", from_act(rt.grad_of(xa)), xd.grad, **TOL[dtype])
+    report("down2_dw", rt.grads["w"].cpu(), wd.grad, rtol=TOL[dtype]["rtol"], atol=1e-3 if dtype == torch.float32 else 5e-2)
+    report("down2_db", rt.grads["b"].cpu(), bd.grad, rtol=1e-4, atol=1e-3)
+    rt.release()
