@@ -2,7 +2,8 @@
 
 Same constructor signatures, attribute names and state_dict layout as the reference classes
 (/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213,
-make_encoder_block :268-323, UNetSimple :651-728),
+make_encoder_block :268-323, make_center :335-372, UNetNaive :373-440, UNetWithoutCenter :443-506,
+UNetSimple :651-728),
 so checkpoints and callers are interchangeable.  The module tree is made of ordinary torch.nn layers
 that only hold the parameters (and serve CPU tensors); for CUDA tensors `forward` hands the
 parameters to the segk tape (segk/engine.py), which launches the HIP kernels: implicit-GEMM
@@ -210,6 +211,149 @@ def make_encoder_block(in_channels, middle_channels, out_channels, convs3=True, 
                         max_pool=max_pool, no_dsam=no_dsam, if_interpolate=if_interpolate, downsc=downsc)
 
 
+def _emit_stem(rt, x, out):
+    """conv1 of the InstanceNorm U-Nets (reference :395-402, :676-683): two conv3x3(bias=False) + InstanceNorm + ReLU groups
+    on the NCHW image; the second writes into `out`."""
+    y = rt.conv_first(x, "conv1.0.weight", None, stats="instance")
+    h = rt.in_up_relu(y, upsample=False)
+    y = rt.conv(h, "conv1.3.weight", stats="instance")
+    return rt.in_up_relu(y, upsample=False, out=out)
+
+
+def _emit_bottom(rt, c4, out):
+    """conv5 of reference :471-480 / :690-699: conv, InstanceNorm (no ReLU), conv, ReLU, conv, InstanceNorm, ReLU.
+    A bias in front of an InstanceNorm cancels: its gradient is exactly zero."""
+    y = rt.conv(c4, "conv5.0.weight", "conv5.0.bias", stats="instance", bias_grad_zero=True)
+    h = rt.in_up_relu(y, upsample=False, relu=False)
+    h = rt.conv(h, "conv5.2.weight", "conv5.2.bias", relu=True)
+    y = rt.conv(h, "conv5.4.weight", "conv5.4.bias", stats="instance", bias_grad_zero=True)
+    return rt.in_up_relu(y, upsample=False, out=out)
+
+
+class CenterBlock(nn.Sequential):
+    """Bottleneck of UNetNaive (reference make_center :335-372): down-sampling, conv3x3 + ReLU, then either a transposed
+    convolution or conv3x3 + bilinear x2, and a ReLU; widths are the reference's literals."""
+
+    def __init__(self, in_channels, max_pool=True, iftrans2d=False):
+        down = nn.MaxPool2d(kernel_size=2, stride=2) if max_pool else nn.Conv2d(in_channels, in_channels, kernel_size=2, stride=2)
+        layers = [down, nn.Conv2d(512, 512, kernel_size=(3, 3), padding=(1, 1)), nn.ReLU(inplace=True)]
+        if iftrans2d:
+            layers += [nn.ConvTranspose2d(512, 256, kernel_size=(4, 4), stride=(2, 2), padding=1)]
+        else:
+            layers += [nn.Conv2d(512, 256, 3, padding=1), nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)]
+        super().__init__(*layers, nn.ReLU(inplace=True))
+        self.max_pool, self.iftrans2d = max_pool, iftrans2d
+
+    def emit(self, rt, prefix, x, out=None):
+        h = rt.pool(x) if self.max_pool else rt.conv_down2(x, prefix + "0.weight", prefix + "0.bias")
+        h = rt.conv(h, prefix + "1.weight", prefix + "1.bias", relu=True)
+        if self.iftrans2d:
+            return rt.conv_transpose_relu(h, prefix + "3.weight", prefix + "3.bias", out=out)
+        y = rt.conv(h, prefix + "3.weight", prefix + "3.bias")
+        return rt.up(y, out=out, align=False, relu=True)
+
+
+def make_center(in_channels, max_pool=True, iftrans2d=False):
+    return CenterBlock(in_channels, max_pool=max_pool, iftrans2d=iftrans2d)
+
+
+def _stem_modules(in_classes, width):
+    return nn.Sequential(
+        nn.Conv2d(in_classes, width, 3, padding=1, bias=False), nn.InstanceNorm2d(width), nn.ReLU(inplace=True),
+        nn.Conv2d(width, width, 3, padding=1, bias=False), nn.InstanceNorm2d(width), nn.ReLU(inplace=True))
+
+
+class UNetNaive(SegkNet):
+    """Five-level InstanceNorm U-Net with a bottleneck (reference :373-440)."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1, if_convtrans=False, ifmaxpool=False):
+        super().__init__()
+        self.patch_train = patch_train
+        self.conv1 = _stem_modules(in_classes, 64)
+        self.conv2 = make_encoder_block(64, 128, 128, convs3=False)
+        self.conv3 = make_encoder_block(128, 256, 256, middle_channels2=256)
+        self.conv4 = make_encoder_block(256, 512, 512, middle_channels2=512)
+        self.conv5 = make_encoder_block(512, 512, 512, middle_channels2=512)
+        self.center = make_center(in_channels=512, max_pool=ifmaxpool, iftrans2d=if_convtrans)
+        self.dec5 = make_decoder_block(256 + 512, 512, 256)
+        self.dec4 = make_decoder_block(256 + 512, 512, 256)
+        self.dec3 = make_decoder_block(256 + 256, 256, 64)
+        self.dec2 = make_decoder_block(64 + 128, 128, 32)
+        self.dec1 = nn.Sequential(nn.Conv2d(32 + 64, 32, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(32, out_classes, kernel_size=1)
+
+    def _forward_host(self, x):
+        skips = [self.conv1(x)]
+        for k in range(2, 6):
+            skips.append(getattr(self, f"conv{k}")(skips[-1]))
+        d = self.center(skips[-1])
+        for k in (5, 4, 3, 2, 1):
+            d = getattr(self, f"dec{k}")(torch.cat([d, skips[k - 1]], 1))
+        return self.final(d)
+
+    def _emit(self, rt, x):
+        N, _, H, W = x.shape
+        if H % 32 or W % 32:
+            raise RuntimeError(f"UNetNaive needs H and W divisible by 32 (five halvings), got {H}x{W}")
+        dec_w = {1: 32, 2: 64, 3: 256, 4: 256, 5: 256}          # width of the decoder tensor that leads concat buffer k
+        enc_w = {1: 64, 2: 128, 3: 256, 4: 512, 5: 512}
+        cat = {k: rt.new(N, H >> (k - 1), W >> (k - 1), dec_w[k] + enc_w[k]).buf for k in range(1, 6)}
+        skips = {1: _emit_stem(rt, x, Act(cat[1], dec_w[1], enc_w[1]))}
+        for k in range(2, 6):
+            skips[k] = getattr(self, f"conv{k}").emit(rt, f"conv{k}.", skips[k - 1], out=Act(cat[k], dec_w[k], enc_w[k]))
+        d = self.center.emit(rt, "center.", skips[5], out=Act(cat[5], 0, dec_w[5]))
+        for k in (5, 4, 3, 2):
+            d = getattr(self, f"dec{k}").emit(rt, f"dec{k}.", [d, skips[k]], out=Act(cat[k - 1], 0, dec_w[k - 1]))
+        e = rt.conv([d, skips[1]], "dec1.0.weight", "dec1.0.bias", relu=True)
+        return rt.head(e, "final.weight", "final.bias")
+
+
+class UNetWithoutCenter(SegkNet):
+    """Four-level InstanceNorm U-Net whose deepest stage stays at 1/8 resolution (reference :443-506)."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1):
+        super().__init__()
+        self.patch_train = patch_train
+        self.conv1 = _stem_modules(in_classes, 64)
+        self.conv2 = make_encoder_block(64, 128, 128, convs3=False)
+        self.conv3 = make_encoder_block(128, 256, 256, middle_channels2=256)
+        self.conv4 = make_encoder_block(256, 512, 512, middle_channels2=512)
+        self.conv5 = nn.Sequential(
+            nn.Conv2d(512, 512, kernel_size=3, padding=1), nn.InstanceNorm2d(512),
+            nn.Conv2d(512, 512, kernel_size=(3, 3), padding=(1, 1)), nn.ReLU(inplace=True),
+            nn.Conv2d(512, 256, kernel_size=3, padding=1), nn.InstanceNorm2d(256), nn.ReLU(inplace=True))
+        self.dec4 = make_decoder_block(256 + 512, 512, 256)
+        self.dec3 = make_decoder_block(256 + 256, 256, 64)
+        self.dec2 = make_decoder_block(64 + 128, 128, 32)
+        self.dec1 = nn.Sequential(nn.Conv2d(32 + 64, 32, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(32, out_classes, kernel_size=1)
+
+    def _forward_host(self, x):
+        skips = [self.conv1(x)]
+        for k in range(2, 5):
+            skips.append(getattr(self, f"conv{k}")(skips[-1]))
+        d = self.conv5(skips[-1])
+        for k in (4, 3, 2, 1):
+            d = getattr(self, f"dec{k}")(torch.cat([d, skips[k - 1]], 1))
+        return self.final(d)
+
+    def _emit(self, rt, x):
+        N, _, H, W = x.shape
+        if H % 8 or W % 8:
+            raise RuntimeError(f"UNetWithoutCenter needs H and W divisible by 8, got {H}x{W}")
+        dec_w = {1: 32, 2: 64, 3: 256, 4: 256}
+        enc_w = {1: 64, 2: 128, 3: 256, 4: 512}
+        cat = {k: rt.new(N, H >> (k - 1), W >> (k - 1), dec_w[k] + enc_w[k]).buf for k in range(1, 5)}
+        skips = {1: _emit_stem(rt, x, Act(cat[1], dec_w[1], enc_w[1]))}
+        for k in range(2, 5):
+            skips[k] = getattr(self, f"conv{k}").emit(rt, f"conv{k}.", skips[k - 1], out=Act(cat[k], dec_w[k], enc_w[k]))
+        d = _emit_bottom(rt, skips[4], Act(cat[4], 0, dec_w[4]))
+        for k in (4, 3, 2):
+            d = getattr(self, f"dec{k}").emit(rt, f"dec{k}.", [d, skips[k]], out=Act(cat[k - 1], 0, dec_w[k - 1]))
+        e = rt.conv([d, skips[1]], "dec1.0.weight", "dec1.0.bias", relu=True)
+        return rt.head(e, "final.weight", "final.bias")
+
+
 class UNetSimple(SegkNet):
     """Four-level U-Net with InstanceNorm and learned stride-2 down-sampling (reference :651-728); `pretrained` is
     accepted and unused, as there."""
@@ -265,19 +409,11 @@ class UNetSimple(SegkNet):
         # concat buffers of reference :720-723, written in place
         cat1, cat2 = level(0, cs // 2 + cs), level(1, cs + 2 * cs)            # [dec2 | conv1], [dec3 | conv2]
         cat3, cat4 = level(2, 4 * cs + 4 * cs), level(3, 8 * cs + 8 * cs)     # [dec4 | conv3], [conv5 | conv4]
-        y = rt.conv_first(x, "conv1.0.weight", None, stats="instance")
-        h = rt.in_up_relu(y, upsample=False)
-        y = rt.conv(h, "conv1.3.weight", stats="instance")
-        c1 = rt.in_up_relu(y, upsample=False, out=Act(cat1, cs // 2, cs))
+        c1 = _emit_stem(rt, x, Act(cat1, cs // 2, cs))
         c2 = self.conv2.emit(rt, "conv2.", c1, out=Act(cat2, cs, 2 * cs))
         c3 = self.conv3.emit(rt, "conv3.", c2, out=Act(cat3, 4 * cs, 4 * cs))
         c4 = self.conv4.emit(rt, "conv4.", c3, out=Act(cat4, 8 * cs, 8 * cs))
-        # a bias in front of an InstanceNorm cancels: its gradient is exactly zero
-        y = rt.conv(c4, "conv5.0.weight", "conv5.0.bias", stats="instance", bias_grad_zero=True)
-        h = rt.in_up_relu(y, upsample=False, relu=False)
-        h = rt.conv(h, "conv5.2.weight", "conv5.2.bias", relu=True)
-        y = rt.conv(h, "conv5.4.weight", "conv5.4.bias", stats="instance", bias_grad_zero=True)
-        c5 = rt.in_up_relu(y, upsample=False, out=Act(cat4, 0, 8 * cs))
+        c5 = _emit_bottom(rt, c4, Act(cat4, 0, 8 * cs))
         d4 = self.dec4.emit(rt, "dec4.", [c5, c4], out=Act(cat3, 0, 4 * cs))
         d3 = self.dec3.emit(rt, "dec3.", [d4, c3], out=Act(cat2, 0, cs))
         d2 = self.dec2.emit(rt, "dec2.", [d3, c2], out=Act(cat1, 0, cs // 2))

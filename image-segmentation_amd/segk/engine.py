@@ -452,12 +452,13 @@ class Runtime:
         self.record(bwd)
         return u
 
-    def up(self, a, out=None, align=True):
-        """Plain bilinear x2 (models/unetplusplus.py:36)."""
+    def up(self, a, out=None, align=True, relu=False):
+        """Plain bilinear x2 (models/unetplusplus.py:36); relu=True: followed by a ReLU (models/unetvgg.py:370-371) whose
+        backward is left to the consumer's data gradient."""
         assert not a.relu_fused, "up-sampling cannot consume a tensor whose ReLU backward is deferred"
         x = a.act
-        u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C))
-        ops.upsample_fwd(x, u.act, stats=None, relu=False, align=align)
+        u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C), relu_fused=relu)
+        ops.upsample_fwd(x, u.act, stats=None, relu=relu, align=align)
 
         def bwd():
             du = self.grad_of(u.act)

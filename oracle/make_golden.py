@@ -226,11 +226,17 @@ def variant_cases(ref):
          lambda: RM.RefUNetSimple(out_classes=3, in_classes=1, channelscale=32), 1),
         ("unetsimple_flat_cs16_c4", lambda: uv.UNetSimple(out_classes=4, in_classes=1, channelscale=16, noupdownsam=True),
          lambda: RM.RefUNetSimple(out_classes=4, in_classes=1, channelscale=16, noupdownsam=True), 1),
+        ("unetnaive_c4", lambda: uv.UNetNaive(out_classes=4, in_classes=1), lambda: RM.RefUNetNaive(out_classes=4, in_classes=1), 1),
+        ("unetnaive_convtrans_pool_c3", lambda: uv.UNetNaive(out_classes=3, in_classes=1, if_convtrans=True, ifmaxpool=True),
+         lambda: RM.RefUNetNaive(out_classes=3, in_classes=1, if_convtrans=True, ifmaxpool=True), 1),
+        ("unetnocenter_c4", lambda: uv.UNetWithoutCenter(out_classes=4, in_classes=1),
+         lambda: RM.RefUNetNaive(out_classes=4, in_classes=1, center=False), 1),
     ]
 
 
 def golden_variants(ref, pin):
-    """UNetSimple (models/unetvgg.py:651-728): default width, half width, and the variant without re-scaling."""
+    """UNetSimple (models/unetvgg.py:651-728): default width, half width, and the variant without re-scaling;
+    UNetNaive (:373-440) with both bottleneck flavours; UNetWithoutCenter (:443-506)."""
     import warnings
     warnings.filterwarnings("ignore", message=".*num_features.*")
     dice_ref, focal_ref = ref["loss.dice"], ref["loss.focal"]

@@ -4,7 +4,8 @@ Plain `torch.nn` restatement of the two graded networks with the reference's sta
 
 * VGG16-BN encoder + five-stage decoder -- /root/reference/models/unetvgg.py:6-41 (decoder block),
   :52-105 (UNetVgg), :158-213 (UNetVggInOut)
-* plain InstanceNorm U-Net              -- /root/reference/models/unetvgg.py:268-323 (encoder block), :651-728 (UNetSimple)
+* plain InstanceNorm U-Nets             -- /root/reference/models/unetvgg.py:268-323 (encoder block), :335-372 (center),
+                                           :373-440 (UNetNaive), :443-506 (UNetWithoutCenter), :651-728 (UNetSimple)
 * nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
 * 3-D DenseNet-BC classifier + DetectMid -- /root/reference/models/densenet3d.py:10-159, 162-186;
                                            /root/reference/models/resnt.py:8-45
@@ -114,6 +115,59 @@ class RefUNetSimple(nn.Module):
         c4 = self.conv4(c3)
         c5 = self.conv5(c4)
         d = self.dec4(torch.cat([c5, c4], 1))
+        d = self.dec3(torch.cat([d, c3], 1))
+        d = self.dec2(torch.cat([d, c2], 1))
+        return self.final(self.dec1(torch.cat([d, c1], 1)))
+
+
+def _in_stem(in_classes, wdt):
+    return nn.Sequential(nn.Conv2d(in_classes, wdt, 3, padding=1, bias=False), nn.InstanceNorm2d(wdt), nn.ReLU(inplace=True),
+                         nn.Conv2d(wdt, wdt, 3, padding=1, bias=False), nn.InstanceNorm2d(wdt), nn.ReLU(inplace=True))
+
+
+def center_block(max_pool, iftrans2d):
+    """unetvgg.py:335-372."""
+    down = nn.MaxPool2d(2, 2) if max_pool else nn.Conv2d(512, 512, kernel_size=2, stride=2)
+    if iftrans2d:
+        tail = [nn.ConvTranspose2d(512, 256, kernel_size=4, stride=2, padding=1)]
+    else:
+        tail = [nn.Conv2d(512, 256, 3, padding=1), nn.Upsample(scale_factor=2, mode='bilinear', align_corners=False)]
+    return nn.Sequential(down, nn.Conv2d(512, 512, 3, padding=1), nn.ReLU(inplace=True), *tail, nn.ReLU(inplace=True))
+
+
+class RefUNetNaive(nn.Module):
+    def __init__(self, out_classes=3, in_classes=1, if_convtrans=False, ifmaxpool=False, center=True):
+        """center=False: UNetWithoutCenter (unetvgg.py:443-506), whose conv5 is a plain stack at 1/8 resolution."""
+        super().__init__()
+        self.conv1 = _in_stem(in_classes, 64)
+        self.conv2 = encoder_block(64, 128, 128, convs3=False)
+        self.conv3 = encoder_block(128, 256, 256, c_mid2=256)
+        self.conv4 = encoder_block(256, 512, 512, c_mid2=512)
+        if center:
+            self.conv5 = encoder_block(512, 512, 512, c_mid2=512)
+            self.center = center_block(ifmaxpool, if_convtrans)
+            self.dec5 = decoder_block(768, 512, 256)
+        else:
+            self.conv5 = nn.Sequential(nn.Conv2d(512, 512, 3, padding=1), nn.InstanceNorm2d(512),
+                                       nn.Conv2d(512, 512, 3, padding=1), nn.ReLU(inplace=True),
+                                       nn.Conv2d(512, 256, 3, padding=1), nn.InstanceNorm2d(256), nn.ReLU(inplace=True))
+        self.dec4 = decoder_block(768, 512, 256)
+        self.dec3 = decoder_block(512, 256, 64)
+        self.dec2 = decoder_block(192, 128, 32)
+        self.dec1 = nn.Sequential(nn.Conv2d(96, 32, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(32, out_classes, 1)
+
+    def forward(self, x):
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c4 = self.conv4(c3)
+        c5 = self.conv5(c4)
+        if hasattr(self, "center"):
+            d = self.dec5(torch.cat([self.center(c5), c5], 1))
+        else:
+            d = c5
+        d = self.dec4(torch.cat([d, c4], 1))
         d = self.dec3(torch.cat([d, c3], 1))
         d = self.dec2(torch.cat([d, c2], 1))
         return self.final(self.dec1(torch.cat([d, c1], 1)))

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import rel_l2, report
+from util import VARIANTS, input_channels, rel_l2, report, variant_oracle, variant_product
 
 pytestmark = pytest.mark.gpu
 
@@ -27,13 +27,8 @@ def build(name):
     if name == "nestedunet_c4":
         from models.unetplusplus import Nested_UNet
         return Nested_UNet(in_ch=1, out_ch=4), 1, 4
-    from models.unetvgg import UNetSimple
-    if name == "unetsimple_c4":
-        return UNetSimple(out_classes=4, in_classes=1), 1, 4
-    if name == "unetsimple_cs32_c3":
-        return UNetSimple(out_classes=3, in_classes=1, channelscale=32), 1, 3
-    if name == "unetsimple_flat_cs16_c4":
-        return UNetSimple(out_classes=4, in_classes=1, channelscale=16, noupdownsam=True), 1, 4
+    if name in VARIANTS:
+        return variant_product(name), 1, 3 if name.endswith("c3") else 4
     raise KeyError(name)
 
 
@@ -55,8 +50,7 @@ def run_step(name, dtype, side=64, n=2, tag=None):
     return model, logits.detach(), loss.detach()
 
 
-MODELS = ["unetvgg_c4", "unetvgg_c3", "unetvgginout_c4", "nestedunet_c4", "unetvgg_c4_convtrans",
-          "unetsimple_c4", "unetsimple_cs32_c3", "unetsimple_flat_cs16_c4"]
+MODELS = ["unetvgg_c4", "unetvgg_c3", "unetvgginout_c4", "nestedunet_c4", "unetvgg_c4_convtrans"] + list(VARIANTS)
 
 
 def oracle_step(name, dtype, side=64, n=2, tag=None, autocast=False):
@@ -66,11 +60,8 @@ def oracle_step(name, dtype, side=64, n=2, tag=None, autocast=False):
     mk = {"unetvgg_c4": lambda: RM.RefUNetVgg(out_classes=4), "unetvgg_c3": lambda: RM.RefUNetVgg(out_classes=3),
           "unetvgg_c4_convtrans": lambda: RM.RefUNetVgg(out_classes=4, if_convtrans=True),
           "unetvgginout_c4": lambda: RM.RefUNetVgg(out_classes=4, in_classes=1),
-          "nestedunet_c4": lambda: RM.RefNestedUNet(in_ch=1, out_ch=4),
-          "unetsimple_c4": lambda: RM.RefUNetSimple(out_classes=4),
-          "unetsimple_cs32_c3": lambda: RM.RefUNetSimple(out_classes=3, channelscale=32),
-          "unetsimple_flat_cs16_c4": lambda: RM.RefUNetSimple(out_classes=4, channelscale=16, noupdownsam=True)}[name]
-    in_ch = 1 if ("inout" in name or "nested" in name or "simple" in name) else 3
+          "nestedunet_c4": lambda: RM.RefNestedUNet(in_ch=1, out_ch=4)}.get(name) or (lambda: variant_oracle(name))
+    in_ch = input_channels(name)
     n_cls = 3 if name.endswith("c3") else 4
     x, t = RM.synthetic_batch(n, side, n_cls, in_ch=in_ch, tag=tag or f"model:{name}")
     m = RM.hash_init_(mk()).to(dtype).train()
@@ -140,8 +131,7 @@ def test_fp32_step_vs_golden(name, golden):
     # eval mode uses the running buffers just updated
     model.eval()
     from oracle.ref_models import synthetic_batch
-    in_ch = 1 if "inout" in name or "nested" in name or "simple" in name else 3
-    x, _ = synthetic_batch(2, 64, 3 if name.endswith("c3") else 4, in_ch=in_ch, tag=f"model:{name}")
+    x, _ = synthetic_batch(2, 64, 3 if name.endswith("c3") else 4, in_ch=input_channels(name), tag=f"model:{name}")
     with torch.no_grad():
         le = model(x.cuda())
     report(f"{name}/eval_logits", le[..., ::4, ::4].cpu(), torch.from_numpy(g[f"{name}/eval_logits_sub"]), rtol=1e-4, atol=1e-4)
@@ -172,7 +162,7 @@ def test_bf16_step_vs_golden(name, golden):
     from oracle import ref_losses as RL
     mauto, _, _ = oracle_step(name, torch.float32, autocast=True)
     from oracle.ref_models import synthetic_batch
-    x, t = synthetic_batch(2, 64, 4, in_ch=1 if "simple" in name else 3, tag=f"model:{name}")
+    x, t = synthetic_batch(2, 64, 4, in_ch=input_channels(name), tag=f"model:{name}")
     with torch.autocast("cpu", dtype=torch.bfloat16):
         la = mauto(x)
     (RL.dice_loss_sq(la.float(), t) + RL.focal_loss_with_logits(la.float(), t)).backward()

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import report
+from util import VARIANTS, input_channels, report, variant_oracle, variant_product
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -95,7 +95,9 @@ def test_oracle_known_answers(golden):
 
 
 def _product(name):
-    from models.unetvgg import UNetSimple, UNetVgg, UNetVggInOut
+    if name in VARIANTS:
+        return variant_product(name)
+    from models.unetvgg import UNetVgg, UNetVggInOut
     from models.unetplusplus import Nested_UNet
     return {
         "unetvgg_c4": lambda: UNetVgg(out_classes=4),
@@ -103,15 +105,14 @@ def _product(name):
         "unetvgg_c4_convtrans": lambda: UNetVgg(out_classes=4, if_convtrans=True),
         "unetvgginout_c4": lambda: UNetVggInOut(in_classes=1, out_classes=4),
         "nestedunet_c4": lambda: Nested_UNet(in_ch=1, out_ch=4),
-        "unetsimple_c4": lambda: UNetSimple(out_classes=4, in_classes=1),
-        "unetsimple_cs32_c3": lambda: UNetSimple(out_classes=3, in_classes=1, channelscale=32),
-        "unetsimple_flat_cs16_c4": lambda: UNetSimple(out_classes=4, in_classes=1, channelscale=16, noupdownsam=True),
         "detectmid": lambda: __import__("models.resnt", fromlist=["DetectMid"]).DetectMid(in_classes=1),
         "detectmid_regr": lambda: __import__("models.resnt", fromlist=["DetectMid"]).DetectMid(in_classes=1, if_regr=True, out_classes=1),
     }[name]()
 
 
 def _oracle(name):
+    if name in VARIANTS:
+        return variant_oracle(name)
     from oracle import ref_models as RM
     return {
         "unetvgg_c4": lambda: RM.RefUNetVgg(out_classes=4),
@@ -119,16 +120,12 @@ def _oracle(name):
         "unetvgg_c4_convtrans": lambda: RM.RefUNetVgg(out_classes=4, if_convtrans=True),
         "unetvgginout_c4": lambda: RM.RefUNetVgg(out_classes=4, in_classes=1),
         "nestedunet_c4": lambda: RM.RefNestedUNet(in_ch=1, out_ch=4),
-        "unetsimple_c4": lambda: RM.RefUNetSimple(out_classes=4),
-        "unetsimple_cs32_c3": lambda: RM.RefUNetSimple(out_classes=3, channelscale=32),
-        "unetsimple_flat_cs16_c4": lambda: RM.RefUNetSimple(out_classes=4, channelscale=16, noupdownsam=True),
         "detectmid": lambda: RM.RefDetectMid(in_classes=1),
         "detectmid_regr": lambda: RM.RefDetectMid(in_classes=1, if_regr=True, out_classes=1),
     }[name]()
 
 
-ALL = ["unetvgg_c4", "unetvgg_c3", "unetvgg_c4_convtrans", "unetvgginout_c4", "nestedunet_c4", "detectmid", "detectmid_regr",
-       "unetsimple_c4", "unetsimple_cs32_c3", "unetsimple_flat_cs16_c4"]
+ALL = ["unetvgg_c4", "unetvgg_c3", "unetvgg_c4_convtrans", "unetvgginout_c4", "nestedunet_c4", "detectmid", "detectmid_regr"] + list(VARIANTS)
 
 
 @pytest.mark.parametrize("name", ALL)
@@ -142,7 +139,7 @@ def test_state_dict_layout_matches_reference(name):
     _product(name).load_state_dict(_oracle(name).state_dict(), strict=True)
 
 
-@pytest.mark.parametrize("name", ["unetvgg_c4", "nestedunet_c4", "unetsimple_cs32_c3"])
+@pytest.mark.parametrize("name", ["unetvgg_c4", "nestedunet_c4", "unetsimple_cs32_c3", "unetnaive_convtrans_pool_c3"])
 def test_oracle_and_host_path_match_golden(name, golden):
     """One train step on CPU: the oracle equals the golden vectors bit for bit, and the product's CPU-tensor
     path (plain torch.nn modules holding the same parameters) equals the oracle."""
@@ -151,7 +148,7 @@ def test_oracle_and_host_path_match_golden(name, golden):
     from loss.dice import dice_loss_sq
     from loss.focal import focal_loss_with_logits
     g = golden["models"]
-    in_ch = 1 if "nested" in name or "simple" in name else 3
+    in_ch = input_channels(name)
     x, t = synthetic_batch(2, 64, 3 if name.endswith("c3") else 4, in_ch=in_ch, tag=f"model:{name}")
     torch.set_num_threads(8)
     m = hash_init_(_oracle(name)).train()
@@ -206,7 +203,10 @@ def test_constructor_surface():
     assert [type(c).__name__ for c in make_decoder_block(8, 16, 4, noupsam=True)] == ["Conv2d", "ReLU", "Conv2d", "InstanceNorm2d", "ReLU"]
     assert blk(torch.zeros(1, 8, 4, 4)).shape == (1, 4, 8, 8)
     assert conv_block_nested(3, 8, 8)(torch.zeros(2, 3, 4, 4)).shape == (2, 8, 4, 4)
-    from models.unetvgg import UNetSimple, make_encoder_block
+    from models.unetvgg import UNetNaive, UNetSimple, UNetWithoutCenter, make_center, make_encoder_block
+    assert [type(c).__name__ for c in make_center(512)] == ["MaxPool2d", "Conv2d", "ReLU", "Conv2d", "Upsample", "ReLU"]
+    assert [type(c).__name__ for c in make_center(512, max_pool=False, iftrans2d=True)] == ["Conv2d", "Conv2d", "ReLU", "ConvTranspose2d", "ReLU"]
+    assert UNetNaive(in_classes=2).conv1[0].in_channels == 2 and UNetWithoutCenter().conv5[4].out_channels == 256
     enc = make_encoder_block(8, 16, 16, middle_channels2=16)
     assert [type(c).__name__ for c in enc] == ["Conv2d"] + ["Conv2d", "InstanceNorm2d", "ReLU"] * 3 and enc[0].stride == (2, 2)
     assert len(make_encoder_block(8, 16, 16, convs3=False, max_pool=True)) == 7

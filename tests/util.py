@@ -23,3 +23,35 @@ def report(name, got, want, rtol, atol):
 def rel_l2(got, want):
     got, want = got.detach().double().cpu(), want.detach().double().cpu()
     return float((got - want).norm() / (want.norm() + 1e-30))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The InstanceNorm U-Net variants of models/unetvgg.py (fixtures in tests/golden/variants.npz): case name ->
+# (product class name, product kwargs, oracle class name, oracle kwargs); all take one input channel.
+# ---------------------------------------------------------------------------------------------------------------
+VARIANTS = {
+    "unetsimple_c4": ("UNetSimple", dict(out_classes=4, in_classes=1), "RefUNetSimple", dict(out_classes=4)),
+    "unetsimple_cs32_c3": ("UNetSimple", dict(out_classes=3, in_classes=1, channelscale=32), "RefUNetSimple", dict(out_classes=3, channelscale=32)),
+    "unetsimple_flat_cs16_c4": ("UNetSimple", dict(out_classes=4, in_classes=1, channelscale=16, noupdownsam=True),
+                                "RefUNetSimple", dict(out_classes=4, channelscale=16, noupdownsam=True)),
+    "unetnaive_c4": ("UNetNaive", dict(out_classes=4, in_classes=1), "RefUNetNaive", dict(out_classes=4)),
+    "unetnaive_convtrans_pool_c3": ("UNetNaive", dict(out_classes=3, in_classes=1, if_convtrans=True, ifmaxpool=True),
+                                    "RefUNetNaive", dict(out_classes=3, if_convtrans=True, ifmaxpool=True)),
+    "unetnocenter_c4": ("UNetWithoutCenter", dict(out_classes=4, in_classes=1), "RefUNetNaive", dict(out_classes=4, center=False)),
+}
+
+
+def variant_product(name):
+    import models.unetvgg as M
+    cls, kw, _, _ = VARIANTS[name]
+    return getattr(M, cls)(**kw)
+
+
+def variant_oracle(name):
+    from oracle import ref_models as RM
+    _, _, cls, kw = VARIANTS[name]
+    return getattr(RM, cls)(**kw)
+
+
+def input_channels(name):
+    return 1 if (name in VARIANTS or "inout" in name or "nested" in name) else 3
