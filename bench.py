@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="slices per GPU")
     ap.add_argument("--side", type=int, default=384)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid"])
+    ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid", "unetsimple"])
     ap.add_argument("--depth", type=int, default=64, help="slices per volume (detectmid)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,6 +157,11 @@ def main():
         from models.unetplusplus import Nested_UNet
         model = Nested_UNet(in_ch=1, out_ch=n_classes)
         gflop = 1859.61
+    elif args.model == "unetsimple":
+        # the configuration the reference trains (roi_train/train_roi.py:39): one input channel, channelscale 128
+        from models.unetvgg import UNetSimple
+        model = UNetSimple(in_classes=1, out_classes=n_classes, channelscale=128)
+        gflop = None                               # taken from the FLOP count the convolution launches report
     else:
         model = UNetVgg(out_classes=n_classes, if_convtrans=args.model == "unetvgg_convtrans")
         gflop = GFLOP_PER_SLICE if args.model == "unetvgg" else 539.05
@@ -170,7 +175,7 @@ def main():
         t = torch.randint(0, min(args.depth, 80), (args.batch,), generator=g).to(device)
     else:
         x, t = synthetic(args.batch, args.side, n_classes, device, seed=20 + rank)
-    if args.model == "unetpp":
+    if args.model in ("unetpp", "unetsimple"):
         x = x[:, :1].contiguous()
 
     def step():
@@ -208,7 +213,7 @@ def main():
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
-    final_loss = float(loss)
+    final_loss = float(loss.detach())
     # host -> device copy of one batch from pinned memory (informational: never part of `value`, inputs are resident)
     hx, ht = x.detach().cpu().pin_memory(), t.cpu().pin_memory()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -227,7 +232,7 @@ def main():
         out = {
             "metric": ("train volumes/sec (fwd+bwd+loss) DenseNet3D-169 DetectMid " + f"{args.depth}x{args.side}x{args.side}") if args.model == "detectmid" else
                       "train slices/sec (fwd+bwd+loss) " + {"unetvgg": "UNet-VGG", "unetvgg_convtrans": "UNet-VGG (transposed-conv decoder)",
-                                                              "unetpp": "UNet++"}[args.model] + f" {args.side}x{args.side}",
+                                                              "unetpp": "UNet++", "unetsimple": "UNetSimple (channelscale 128)"}[args.model] + f" {args.side}x{args.side}",
             "value": round(value, 2), "unit": "volumes/s" if args.model == "detectmid" else "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
@@ -250,6 +255,8 @@ def main():
                 ms_, fl_, n_ = fam.get(name, (0.0, 0.0, 0))
                 fam[name] = (ms_ + a.elapsed_time(b), fl_ + fl, n_ + 1)
             conv_ms = (fwd + wg) / timed_steps
+            if gflop is None:      # FLOP as launched (channel padding included), per slice
+                gflop = sum(fl for _, _, _, fl, _ in timer) / timed_steps / args.batch / 1e9
             achieved = gflop * args.batch / conv_ms        # GFLOP / ms = TFLOP/s
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             # HBM bytes of the same launches (one step) from the committed PMC passes of this workload; null for other workloads
@@ -272,6 +279,8 @@ def main():
                                              for name, (ms_, fl_, n_) in sorted(fam.items()) if ms_ > 0}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_detectmid(args.depth, args.side) if args.model == "detectmid" else cpu_baseline(n_classes)
+            if args.model not in ("unetvgg", "detectmid"):
+                out["cpu_baseline"]["sample"] += " (the headline UNet-VGG workload, not this model)"
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

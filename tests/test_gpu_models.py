@@ -285,3 +285,33 @@ def test_weight_gradients_on_side_stream(monkeypatch):
         grads.append([p.grad.clone() for p in model.parameters()] + [logits, loss])
     for a, b in zip(*grads):
         assert torch.equal(a, b)
+
+
+def test_unetsimple_reference_width_vs_oracle():
+    """UNetSimple as the reference trains it (roi_train/train_roi.py:39,52: one input channel, channelscale 128, up to
+    1024-wide layers and a 2048-channel concat): fp32 logits, loss and the last layers' gradients against the oracle on
+    the same weights; bf16 logits within the bound of the bf16 network test."""
+    from loss.dice import dice_loss_sq
+    from models.unetvgg import UNetSimple
+    from oracle import ref_losses as RL
+    from oracle.ref_models import RefUNetSimple, hash_init_, synthetic_batch
+    x, t = synthetic_batch(2, 96, 2, in_ch=1, tag="model:unetsimple128")
+    ref = hash_init_(RefUNetSimple(out_classes=2, channelscale=128)).train()
+    want = ref(x)
+    lw = RL.dice_loss_sq(want, t)
+    lw.backward()
+    model = hash_init_(UNetSimple(in_classes=1, channelscale=128, out_classes=2)).cuda().train().set_compute_dtype(torch.float32)
+    got = model(x.cuda())
+    loss = dice_loss_sq(got, t.cuda())
+    loss.backward()
+    report("unetsimple128/logits", got.detach().cpu(), want.detach(), rtol=1e-4, atol=1e-4)
+    report("unetsimple128/loss", loss.detach().cpu(), lw.detach(), rtol=1e-4, atol=1e-6)
+    for (k, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+        if k.startswith(("final.", "dec1.0.")):
+            assert rel_l2(p.grad.cpu(), q.grad) < 1e-4, k
+        elif float(q.grad.norm()) > 1e-6:
+            assert rel_l2(p.grad.cpu(), q.grad) < 5e-2, (k, rel_l2(p.grad.cpu(), q.grad))
+    model.set_compute_dtype(torch.bfloat16)
+    with torch.no_grad():
+        e = rel_l2(model(x.cuda()).cpu(), want.detach())
+    assert e < 5e-2, e
