@@ -25,6 +25,10 @@ _PROTOS = {
     "segk_dice_focal_finalize": (I, [P, P, L, L, L, I, P, I, P]),
     "segk_dice_focal_bwd": (I, [P, I, P, P, L, L, L, F, P, I, P, P, P, P, P, I, P]),
     "segk_argmax_dice": (I, [P, I, P, L, L, L, P, P, P, I, P]),
+    "segk_edge_workspace": (Z, [L, L, L]),
+    "segk_edge_bwd_workspace": (Z, [L, L, L]),
+    "segk_edge_fwd": (I, [P, L, L, L, F, P, P, P, Z, I, P]),
+    "segk_edge_bwd": (I, [P, P, P, L, L, L, P, P, Z, I, P]),
     "segk_nchw_to_nhwc": (I, [P, L, L, L, L, P, I, L, L, I, P]),
     "segk_im2col3x3": (I, [P, L, L, L, L, P, I, L, L, I, P]),
     "segk_conv_krow": (I, [I]),

@@ -179,6 +179,73 @@ def focal_loss_with_logits(p, t, gamma=2., alpha=None, reduction='elementwise_me
 
 
 # ------------------------------------------------------------------------------------ CPU tensors
+
+# ------------------------------------------------------------------------------------ public: edge-aware Dice
+class _EdgeFn(torch.autograd.Function):
+    """fp32 [N,C,H,W] -> edge map |IN(sobel_x)| + |IN(sobel_y)| per channel (segk_edge_fwd / segk_edge_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _lib.lib()
+        xf = x.contiguous().float()
+        N, C, H, W = xf.shape
+        dev, st = _env(xf)
+        edge = torch.empty_like(xf)
+        stats = torch.empty(N * C * 4, dtype=torch.float32, device=xf.device)
+        ws = workspace(query("segk_edge_workspace", N * C, H, W), xf.device)
+        call("segk_edge_fwd", xf.data_ptr(), N * C, H, W, 1e-5, edge.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws.numel(), dev, st)
+        ctx.save_for_backward(xf, stats)
+        ctx.in_dtype = x.dtype
+        return edge
+
+    @staticmethod
+    def backward(ctx, dedge):
+        xf, stats = ctx.saved_tensors
+        N, C, H, W = xf.shape
+        dev, st = _env(xf)
+        g = dedge.contiguous().float()
+        dx = torch.empty_like(xf)
+        ws = workspace(query("segk_edge_bwd_workspace", N * C, H, W), xf.device)
+        call("segk_edge_bwd", xf.data_ptr(), g.data_ptr(), stats.data_ptr(), N * C, H, W, dx.data_ptr(), ws.data_ptr(), ws.numel(), dev, st)
+        return dx.to(ctx.in_dtype)
+
+
+def get_hot_enc(input, channels=3):
+    """One-hot planes of a label image (reference loss/edge_loss.py:32-55; 3-D input is reshaped with shape[2] twice, as there)."""
+    if input.dim() == 2:
+        input = input.unsqueeze(0).unsqueeze(0)
+    if input.dim() == 3:
+        input = input.view(input.shape[0], 1, input.shape[2], input.shape[2])
+    zer = torch.zeros(input.shape[0], channels, *input.shape[2:], device=input.device)
+    return zer.scatter(1, input.long(), 1)
+
+
+def get_edg_c(tens):
+    """Per-channel edge map (reference loss/hausdorff.py:71-108): Sobel derivatives in both directions and both signs,
+    each through InstanceNorm2d and ReLU, summed."""
+    if tens.dim() == 3:
+        tens = tens.float().unsqueeze(1)
+    if tens.is_cuda:
+        return _EdgeFn.apply(tens)
+    return _host_edges(tens)
+
+
+def edge_conv_loss(probs, act):
+    """Squared-Dice loss between the edge maps of the prediction and of the one-hot target (reference
+    loss/hausdorff.py:110-128; three classes, as get_hot_enc's default there)."""
+    return dice_loss_sq(get_edg_c(probs), get_edg_c(get_hot_enc(act)))
+
+
+def _host_edges(x):
+    """CPU tensors: the derivative pair as one grouped convolution with two filters per channel; the opposite-sign pair
+    of the reference is the negation, and relu(IN(s)) + relu(IN(-s)) = |IN(s)|."""
+    C = x.shape[1]
+    pair = torch.tensor([[[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]], [[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]]], dtype=x.dtype)
+    s = F.conv2d(x, pair.unsqueeze(1).repeat(C, 1, 1, 1).to(x.device), padding=1, groups=C)      # [N, 2C, H, W]: (x, y) per channel
+    u = F.instance_norm(s, eps=1e-5).abs()
+    return u[:, 0::2] + u[:, 1::2]
+
+
 def _host_onehot(labels, n_classes):
     idx = _as_square_labels(labels)
     return torch.zeros(idx.shape[0], n_classes, idx.shape[2], idx.shape[3]).scatter(1, idx, 1)

@@ -372,6 +372,19 @@ int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void* dst, int64
 int segk_block2(int dtype, void* x, int64_t ldx, void* wide, int64_t ld_wide, int64_t N, int64_t H, int64_t W,
                 int64_t C, int flags, int dev, void* stream);
 
+/* Edge map of an fp32 [planes, H, W] tensor (planes = N*C): per plane the two Sobel derivatives (zero padding), each
+ * instance-normalised (biased variance, eps), rectified in both directions and summed:
+ *     edge = |IN(sobel_x)| + |IN(sobel_y)|;   stats[plane] = (mean_x, rstd_x, mean_y, rstd_y) is kept for the backward.
+ * segk_edge_bwd: dx = d loss / d x from dedge = d loss / d edge (same shape).
+ * replaces: get_edg_c, loss/hausdorff.py:71-108 (four grouped F.conv2d + nn.InstanceNorm2d + ReLU), the operator
+ * behind edge_conv_loss (:110-128), whose Dice part is segk_dice_focal_* with a float target.        */
+size_t segk_edge_workspace(int64_t planes, int64_t H, int64_t W);
+size_t segk_edge_bwd_workspace(int64_t planes, int64_t H, int64_t W);
+int segk_edge_fwd(const float* x, int64_t planes, int64_t H, int64_t W, float eps, float* edge, float* stats,
+                  void* workspace, size_t workspace_bytes, int dev, void* stream);
+int segk_edge_bwd(const float* x, const float* dedge, const float* stats, int64_t planes, int64_t H, int64_t W,
+                  float* dx, void* workspace, size_t workspace_bytes, int dev, void* stream);
+
 /* Fused multi-tensor Adam step (torch.optim.Adam defaults; perlosstrain/naive_train.py:397-398,
  * pl_utils/pl_mod.py:109-110).  One flat fp32 parameter / gradient / moment buffer.                */
 int segk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,

@@ -4,7 +4,7 @@ Run in the build container only (needs /root/reference):
 
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
 
-It puts oracle/stubs (stand-ins for the absent torchvision / rising / pytorch_lightning packages)
+It puts oracle/stubs (stand-ins for the absent torchvision / rising / pytorch_lightning / scikit-image packages)
 and /root/reference on sys.path, imports the reference's models/unetvgg.py, models/unetplusplus.py,
 loss/dice.py and loss/focal.py, runs them on hash-initialised weights and synthetic batches, and
 
@@ -126,6 +126,33 @@ def golden_aux_losses(ref, pin):
             out[f"{name}/{tag}"] = la.detach().numpy()
             out[f"{name}/{tag}_grad"] = a.grad.numpy()
     np.savez_compressed(os.path.join(GOLD, "losses_aux.npz"), **out)
+
+
+def golden_edge_losses(pin):
+    """Edge-aware Dice (loss/hausdorff.py:71-128) on the three-class loss cases: edge map of the logits, loss, dlogits."""
+    import importlib
+    hd = importlib.import_module("loss.hausdorff")
+    assert hd.__file__.startswith(REF), hd.__file__
+    out = {}
+    for name, C, N, side, kw in loss_cases():
+        if C != 3:
+            continue
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        a = z.clone().requires_grad_(True)
+        ea = hd.get_edg_c(a)
+        la = hd.edge_conv_loss(a, t)
+        la.backward()
+        b = z.clone().requires_grad_(True)
+        eb = RL.get_edg_c(b)
+        lb = RL.edge_conv_loss(b, t)
+        lb.backward()
+        pin[f"loss/{name}/edge"] = bool(bits_equal(ea.detach(), eb.detach()) and bits_equal(la.detach(), lb.detach()) and bits_equal(a.grad, b.grad)
+                                        and bits_equal(hd.get_edg_c(hd.get_hot_enc(t)), RL.get_edg_c(RL.get_hot_enc(t))))
+        out[f"{name}/edge_map"] = ea.detach().numpy()
+        out[f"{name}/edge_target"] = hd.get_edg_c(hd.get_hot_enc(t)).numpy()
+        out[f"{name}/edge_loss"] = la.detach().numpy()
+        out[f"{name}/edge_grad"] = a.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "losses_edge.npz"), **out)
 
 
 # ------------------------------------------------------------------------------------ models
@@ -309,7 +336,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
     pin = {}
-    partial = [a for a in ("--volumes-only", "--aux-losses-only", "--variants-only") if a in sys.argv]
+    partial = [a for a in ("--volumes-only", "--aux-losses-only", "--variants-only", "--edge-losses-only") if a in sys.argv]
     if partial:                           # refresh one fixture file without regenerating the others
         pf = os.path.join(GOLD, "oracle_pin.json")
         pin = json.load(open(pf))["checks"] if os.path.exists(pf) else {}
@@ -319,9 +346,12 @@ def main():
             golden_aux_losses(ref, pin)
         if "--variants-only" in partial:
             golden_variants(ref, pin)
+        if "--edge-losses-only" in partial:
+            golden_edge_losses(pin)
     else:
         golden_losses(ref, pin)
         golden_aux_losses(ref, pin)
+        golden_edge_losses(pin)
         golden_models(ref, pin)
         golden_variants(ref, pin)
         golden_volumes(ref, pin)

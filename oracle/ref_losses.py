@@ -7,6 +7,7 @@ reference code evaluates (not from its text):
 * self-adjusting Dice, log-cosh Dice -- /root/reference/loss/dice.py:275-349
 * arg-max Dice metric      -- /root/reference/loss/dice.py:89-184
 * multi-class focal loss   -- /root/reference/loss/focal.py:32-75, 108-137
+* edge-aware Dice          -- /root/reference/loss/hausdorff.py:71-128, /root/reference/loss/edge_loss.py:32-55
 
 Pinned by `oracle/make_golden.py`, which imports the reference itself in the build container and
 checks these functions against it bit for bit; the recorded outputs live in tests/golden/.
@@ -14,6 +15,7 @@ Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke() may import 
 """
 import torch
 import torch.nn.functional as F
+from torch import nn
 
 
 def _one_hot(labels, n_classes, dtype=torch.float32):
@@ -109,6 +111,37 @@ def focal_loss_with_logits(p, t, gamma=2., alpha=None, reduction='elementwise_me
     if reduction == 'sum':
         return out.sum()
     raise ValueError('Reduction parameter unknown.')
+
+
+
+# ---------------------------------------------------------------------------------------------
+# Edge-aware Dice (/root/reference/loss/hausdorff.py:71-128, /root/reference/loss/edge_loss.py:32-55)
+# ---------------------------------------------------------------------------------------------
+def get_hot_enc(labels, channels=3):
+    if labels.dim() == 2:
+        labels = labels[None, None]
+    if labels.dim() == 3:
+        labels = labels.view(labels.shape[0], 1, labels.shape[2], labels.shape[2])
+    return torch.zeros(labels.shape[0], channels, *labels.shape[2:], device=labels.device).scatter(1, labels.long(), 1)
+
+
+def get_edg_c(tens):
+    """Four depthwise Sobel responses (x, -x, y, -y), each InstanceNorm2d'ed and rectified, summed in the reference's order."""
+    if tens.dim() == 3:
+        tens = tens.float().unsqueeze(1)
+    C = tens.shape[1]
+    gx = torch.tensor([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=torch.float32)
+    gy = torch.tensor([[1, 2, 1], [0, 0, 0], [-1, -2, -1]], dtype=torch.float32)
+    norm, out = nn.InstanceNorm2d(C), None
+    for k in (gx, -gx, gy, -gy):
+        w = k.unsqueeze(0).expand(C, 1, 3, 3).to(tens.device)
+        r = torch.relu(norm(F.conv2d(tens, w, stride=1, padding=1, groups=C)))
+        out = r if out is None else out + r
+    return out
+
+
+def edge_conv_loss(probs, act):
+    return dice_loss_sq(get_edg_c(probs), get_edg_c(get_hot_enc(act)))
 
 
 def dice_focal_closed_form_grad(logits, labels, gamma=2.0, w_dice=1.0, w_focal=1.0):

@@ -150,3 +150,56 @@ def test_self_adjusting_and_logcosh_dice_vs_golden(case):
         report(f"{name}/{tag}", loss.detach().cpu(), torch.from_numpy(g[f"{name}/{tag}"]), rtol=1e-5, atol=1e-6)
         want = torch.from_numpy(g[f"{name}/{tag}_grad"])
         report(f"{name}/{tag}_grad", a.grad.cpu(), want, rtol=1e-4, atol=1e-4 * float(want.abs().max()) + 1e-12)
+
+
+def test_edge_dice_loss_vs_golden():
+    """edge_conv_loss / get_edg_c (reference loss/hausdorff.py:71-128) on the HIP edge kernels + the fused Dice kernels:
+    edge map, loss and dlogits against the vectors captured from the reference (tests/golden/losses_edge.npz)."""
+    import os
+    from oracle.cases import loss_cases
+    from loss.edge_loss import get_hot_enc
+    from loss.hausdorff import edge_conv_loss, get_edg_c
+    from segk import _lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses_edge.npz"))
+    for name, C, N, side, kw in loss_cases():
+        if f"{name}/edge_loss" not in g.files:
+            continue
+        z, t = _inputs(name, C, N, side, kw)
+        a = z.clone().cuda().requires_grad_(True)
+        before = _lib.launches
+        report(f"{name}/edge_map", get_edg_c(a).detach().cpu(), torch.from_numpy(g[f"{name}/edge_map"]), rtol=1e-4, atol=1e-5)
+        report(f"{name}/edge_target", get_edg_c(get_hot_enc(t.cuda())).cpu(), torch.from_numpy(g[f"{name}/edge_target"]), rtol=1e-4, atol=1e-5)
+        loss = edge_conv_loss(a, t.cuda())
+        loss.backward()
+        assert _lib.launches - before >= 6, "the HIP library did not run the loss"
+        report(f"{name}/edge_loss", loss.detach().cpu(), torch.from_numpy(g[f"{name}/edge_loss"]), rtol=1e-5, atol=1e-6)
+        want = torch.from_numpy(g[f"{name}/edge_grad"])
+        report(f"{name}/edge_grad", a.grad.cpu(), want, rtol=1e-4, atol=1e-4 * float(want.abs().max()))
+
+
+def test_edge_map_operator_vs_oracle():
+    """The edge operator alone on a non-square, multi-plane input with an arbitrary upstream gradient, against the oracle
+    in fp64; two runs give identical bits."""
+    from oracle import ref_losses as RL
+    from loss.hausdorff import get_edg_c
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 5, 37, 50, generator=gen)
+    up = torch.randn(3, 5, 37, 50, generator=gen)
+    a = x.clone().double().requires_grad_(True)
+    # fp64 oracle: the restatement builds fp32 filters, so evaluate it through torch's double kernels explicitly
+    import torch.nn.functional as F
+    kx = torch.tensor([[-1., 0., 1.], [-2., 0., 2.], [-1., 0., 1.]], dtype=torch.float64)
+    ky = torch.tensor([[1., 2., 1.], [0., 0., 0.], [-1., -2., -1.]], dtype=torch.float64)
+    want = sum(torch.relu(F.instance_norm(F.conv2d(a, k.expand(5, 1, 3, 3), padding=1, groups=5), eps=1e-5)) for k in (kx, -kx, ky, -ky))
+    want.backward(up.double())
+    outs = []
+    for _ in range(2):
+        b = x.clone().cuda().requires_grad_(True)
+        e = get_edg_c(b)
+        e.backward(up.cuda())
+        outs.append((e.detach().clone(), b.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    report("edge_map", outs[0][0].cpu(), want.detach().float(), rtol=1e-4, atol=1e-5)
+    report("edge_dx", outs[0][1].cpu(), a.grad.float(), rtol=1e-4, atol=1e-4 * float(a.grad.abs().max()))
+    # fp32 oracle agrees with its fp64 evaluation to the same tolerance (sanity of the comparison itself)
+    report("oracle32", RL.get_edg_c(x), want.detach().float(), rtol=1e-4, atol=1e-5)

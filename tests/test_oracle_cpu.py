@@ -76,6 +76,36 @@ def test_aux_dice_losses_oracle_and_host_path():
     assert seen >= 5
 
 
+def test_edge_dice_loss_oracle_and_host_path():
+    """Edge-aware Dice (loss/hausdorff.py:71-128): the oracle reproduces the reference's vectors bit for bit and the
+    product's CPU-tensor path (one grouped convolution, |InstanceNorm|) agrees with it."""
+    from oracle import ref_losses as RL
+    from oracle.cases import loss_cases, make_loss_inputs
+    from loss.edge_loss import get_hot_enc
+    from loss.hausdorff import edge_conv_loss, get_edg_c
+    g = np.load(os.path.join(ROOT, "tests", "golden", "losses_edge.npz"))
+    seen = 0
+    for name, C, N, side, kw in loss_cases():
+        if f"{name}/edge_loss" not in g.files:
+            continue
+        seen += 1
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        a = z.clone().requires_grad_(True)
+        la = RL.edge_conv_loss(a, t)
+        la.backward()
+        assert np.array_equal(RL.get_edg_c(z).numpy(), g[f"{name}/edge_map"]) and np.array_equal(la.detach().numpy(), g[f"{name}/edge_loss"])
+        assert np.array_equal(a.grad.numpy(), g[f"{name}/edge_grad"])
+        assert torch.equal(get_hot_enc(t), RL.get_hot_enc(t))
+        b = z.clone().requires_grad_(True)
+        report(f"{name}/edge host map", get_edg_c(b), torch.from_numpy(g[f"{name}/edge_map"]), rtol=1e-5, atol=1e-5)
+        lb = edge_conv_loss(b, t)
+        lb.backward()
+        report(f"{name}/edge host", lb, la, rtol=1e-5, atol=1e-6)
+        report(f"{name}/edge host grad", b.grad, a.grad, rtol=1e-4, atol=1e-4 * float(a.grad.abs().max()))
+    assert seen == 2
+    assert get_edg_c(torch.zeros(2, 8, 8)).shape == (2, 1, 8, 8)          # label images become one plane
+
+
 def test_oracle_known_answers(golden):
     from oracle import ref_losses as RL
     z = torch.zeros(2, 4, 8, 8)
