@@ -120,6 +120,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    if os.environ.get("SEGK_BENCH_TRACE_AFTER"):      # debugging aid: dump every thread's Python stack and exit if still running after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["SEGK_BENCH_TRACE_AFTER"]), exit=True)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -3,7 +3,7 @@
 Same constructor signatures, attribute names and state_dict layout as the reference classes
 (/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213,
 make_encoder_block :268-323, make_center :335-372, UNetNaive :373-440, UNetWithoutCenter :443-506,
-UNetSimple :651-728),
+UNetNaiveMultiOut :509-574, UNetLimMultiOut :576-648, UNetSimple :651-728),
 so checkpoints and callers are interchangeable.  The module tree is made of ordinary torch.nn layers
 that only hold the parameters (and serve CPU tensors); for CUDA tensors `forward` hands the
 parameters to the segk tape (segk/engine.py), which launches the HIP kernels: implicit-GEMM
@@ -338,20 +338,109 @@ class UNetWithoutCenter(SegkNet):
         return self.final(d)
 
     def _emit(self, rt, x):
-        N, _, H, W = x.shape
-        if H % 8 or W % 8:
-            raise RuntimeError(f"UNetWithoutCenter needs H and W divisible by 8, got {H}x{W}")
-        dec_w = {1: 32, 2: 64, 3: 256, 4: 256}
-        enc_w = {1: 64, 2: 128, 3: 256, 4: 512}
-        cat = {k: rt.new(N, H >> (k - 1), W >> (k - 1), dec_w[k] + enc_w[k]).buf for k in range(1, 5)}
-        skips = {1: _emit_stem(rt, x, Act(cat[1], dec_w[1], enc_w[1]))}
+        return _emit_unet4(self, rt, x, {1: 64, 2: 128, 3: 256, 4: 512}, {1: 32, 2: 64, 3: 256, 4: 256}, _emit_bottom)[0]
+
+
+def _emit_bottom_plain(rt, c4, out):
+    """conv5 of reference :539-548 / :611-620: two conv3x3(bias=False) + InstanceNorm + ReLU groups."""
+    y = rt.conv(c4, "conv5.0.weight", stats="instance")
+    h = rt.in_up_relu(y, upsample=False)
+    y = rt.conv(h, "conv5.3.weight", stats="instance")
+    return rt.in_up_relu(y, upsample=False, out=out)
+
+
+def _emit_unet4(net, rt, x, enc_w, dec_w, bottom):
+    """Shared body of the four-level InstanceNorm U-Nets.  enc_w[k] / dec_w[k]: widths of the encoder skip and of the
+    decoder tensor that share concat buffer k (1 = full resolution; the torch.cat of reference :501-504 in place).
+    -> (logits, encoder skips {1..4}, decoder tensors {5: conv5, 4: dec4, 3: dec3, 2: dec2, 1: dec1})"""
+    N, _, H, W = x.shape
+    if H % 8 or W % 8:
+        raise RuntimeError(f"{type(net).__name__} needs H and W divisible by 8 (three stride-2 convolutions), got {H}x{W}")
+    cat = {k: rt.new(N, H >> (k - 1), W >> (k - 1), dec_w[k] + enc_w[k]).buf for k in range(1, 5)}
+    skips = {1: _emit_stem(rt, x, Act(cat[1], dec_w[1], enc_w[1]))}
+    for k in range(2, 5):
+        skips[k] = getattr(net, f"conv{k}").emit(rt, f"conv{k}.", skips[k - 1], out=Act(cat[k], dec_w[k], enc_w[k]))
+    dec = {5: bottom(rt, skips[4], Act(cat[4], 0, dec_w[4]))}
+    for k in (4, 3, 2):
+        dec[k] = getattr(net, f"dec{k}").emit(rt, f"dec{k}.", [dec[k + 1], skips[k]], out=Act(cat[k - 1], 0, dec_w[k - 1]))
+    dec[1] = rt.conv([dec[2], skips[1]], "dec1.0.weight", "dec1.0.bias", relu=True)
+    return rt.head(dec[1], "final.weight", "final.bias"), skips, dec
+
+
+class UNetNaiveMultiOut(SegkNet):
+    """UNetWithoutCenter with a bias-free bottom stage; also returns [conv3, dec4] (reference :509-574)."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1):
+        super().__init__()
+        self.patch_train = patch_train
+        self.conv1 = _stem_modules(in_classes, 64)
+        self.conv2 = make_encoder_block(64, 128, 128, convs3=False)
+        self.conv3 = make_encoder_block(128, 256, 256, middle_channels2=256)
+        self.conv4 = make_encoder_block(256, 512, 512, middle_channels2=512)
+        self.conv5 = nn.Sequential(
+            nn.Conv2d(512, 512, kernel_size=3, padding=1, bias=False), nn.InstanceNorm2d(512), nn.ReLU(inplace=True),
+            nn.Conv2d(512, 256, kernel_size=3, padding=1, bias=False), nn.InstanceNorm2d(256), nn.ReLU(inplace=True))
+        self.dec4 = make_decoder_block(256 + 512, 512, 256)
+        self.dec3 = make_decoder_block(256 + 256, 256, 64)
+        self.dec2 = make_decoder_block(64 + 128, 128, 32)
+        self.dec1 = nn.Sequential(nn.Conv2d(32 + 64, 32, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(32, out_classes, kernel_size=1)
+
+    def _forward_host(self, x):
+        skips = [self.conv1(x)]
         for k in range(2, 5):
-            skips[k] = getattr(self, f"conv{k}").emit(rt, f"conv{k}.", skips[k - 1], out=Act(cat[k], dec_w[k], enc_w[k]))
-        d = _emit_bottom(rt, skips[4], Act(cat[4], 0, dec_w[4]))
-        for k in (4, 3, 2):
-            d = getattr(self, f"dec{k}").emit(rt, f"dec{k}.", [d, skips[k]], out=Act(cat[k - 1], 0, dec_w[k - 1]))
-        e = rt.conv([d, skips[1]], "dec1.0.weight", "dec1.0.bias", relu=True)
-        return rt.head(e, "final.weight", "final.bias")
+            skips.append(getattr(self, f"conv{k}")(skips[-1]))
+        dec4 = self.dec4(torch.cat([self.conv5(skips[-1]), skips[3]], 1))
+        d = self.dec3(torch.cat([dec4, skips[2]], 1))
+        d = self.dec2(torch.cat([d, skips[1]], 1))
+        return self.final(self.dec1(torch.cat([d, skips[0]], 1))), [skips[2], dec4]
+
+    def _emit(self, rt, x):
+        logits, skips, dec = _emit_unet4(self, rt, x, {1: 64, 2: 128, 3: 256, 4: 512}, {1: 32, 2: 64, 3: 256, 4: 256}, _emit_bottom_plain)
+        return logits, [rt.export(skips[3]), rt.export(dec[4])]
+
+
+class UNetLimMultiOut(SegkNet):
+    """Four-level U-Net whose layers all have `channel_depth` channels; with multiout also returns conv3 (reference :576-648)."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1, channel_depth=16, multiout=False):
+        super().__init__()
+        cd = channel_depth
+        self.multiout, self.patch_train, self.channel_depth = multiout, patch_train, cd
+        # InstanceNorm2d widths are the reference's literals; without affine parameters the width is unused
+        self.conv1 = nn.Sequential(
+            nn.Conv2d(in_classes, cd, 3, padding=1, bias=False), nn.InstanceNorm2d(64), nn.ReLU(inplace=True),
+            nn.Conv2d(cd, cd, 3, padding=1, bias=False), nn.InstanceNorm2d(64), nn.ReLU(inplace=True))
+        self.conv2 = make_encoder_block(cd, cd, cd, convs3=False)
+        self.conv3 = make_encoder_block(cd, cd, cd, middle_channels2=cd)
+        self.conv4 = make_encoder_block(cd, cd, cd, middle_channels2=cd)
+        self.conv5 = nn.Sequential(
+            nn.Conv2d(cd, cd, kernel_size=3, padding=1, bias=False), nn.InstanceNorm2d(cd), nn.ReLU(inplace=True),
+            nn.Conv2d(cd, cd // 2, kernel_size=3, padding=1, bias=False), nn.InstanceNorm2d(cd), nn.ReLU(inplace=True))
+        self.dec4 = make_decoder_block(cd + cd // 2, cd, cd // 2)
+        self.dec3 = make_decoder_block(cd + cd // 2, cd, cd // 2)
+        self.dec2 = make_decoder_block(cd + cd // 2, cd, cd // 2)
+        self.dec1 = nn.Sequential(nn.Conv2d(cd + cd // 2, cd, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(cd, out_classes, kernel_size=1)
+
+    def _forward_host(self, x):
+        skips = [self.conv1(x)]
+        for k in range(2, 5):
+            skips.append(getattr(self, f"conv{k}")(skips[-1]))
+        d = self.conv5(skips[-1])
+        for k in (4, 3, 2, 1):
+            d = getattr(self, f"dec{k}")(torch.cat([d, skips[k - 1]], 1))
+        return (self.final(d), skips[2]) if self.multiout else self.final(d)
+
+    def _pack_outputs(self, logits, feats):
+        return logits, feats[0]
+
+    def _emit(self, rt, x):
+        cd = self.channel_depth
+        if cd % 16:
+            raise NotImplementedError("channel_depth must be a multiple of 16 (8-channel storage groups)")
+        logits, skips, _ = _emit_unet4(self, rt, x, {k: cd for k in range(1, 5)}, {k: cd // 2 for k in range(1, 5)}, _emit_bottom_plain)
+        return (logits, [rt.export(skips[3])]) if self.multiout else logits
 
 
 class UNetSimple(SegkNet):
@@ -395,8 +484,6 @@ class UNetSimple(SegkNet):
         return self.final(dec1)
 
     def _emit(self, rt, x):
-        if self.multiout:
-            raise NotImplementedError("the HIP tape returns the logits only; construct with multiout=False")
         N, _, H, W = x.shape
         cs, down = self.channelscale, not self.noupdownsam
         if cs % 16:
@@ -418,4 +505,5 @@ class UNetSimple(SegkNet):
         d3 = self.dec3.emit(rt, "dec3.", [d4, c3], out=Act(cat2, 0, cs))
         d2 = self.dec2.emit(rt, "dec2.", [d3, c2], out=Act(cat1, 0, cs // 2))
         e = rt.conv([d2, c1], "dec1.0.weight", "dec1.0.bias", relu=True)
-        return rt.head(e, "final.weight", "final.bias")
+        logits = rt.head(e, "final.weight", "final.bias")
+        return (logits, [rt.export(v) for v in (e, d2, d3, d4)]) if self.multiout else logits

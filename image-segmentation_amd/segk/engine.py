@@ -59,6 +59,7 @@ class Runtime:
         self.zero_state = zero_state if grad_alloc is not None else None
         self.counters = []                      # BatchNorm num_batches_tracked buffers to bump once, together
         self.pack_plan = None                   # segk.packplan.PackPlan of the network (None: pack layer by layer)
+        self.exports = []                       # intermediate tensors handed to the caller next to the logits
 
     # ---------------------------------------------------------------- buffers
     def new(self, N, H, W, C, zero=False):
@@ -151,6 +152,25 @@ class Runtime:
     def backward(self):
         self.backward_keep()
         self.release()
+
+    # ---------------------------------------------------------------- extra outputs
+    def export(self, var):
+        """fp32 NCHW copy of an intermediate tensor for networks that return feature maps next to their logits
+        (models/unetvgg.py:574,646,726); its gradient re-enters the tape through `import_gradients`."""
+        self.exports.append(var)
+        return var.act.nchw().float().contiguous()
+
+    def import_gradients(self, grads):
+        """Add the callers' gradients of the exported tensors (None: unused) to the tape's gradient buffers.  Runs after
+        the head's backward and before the recorded closures."""
+        for var, g in zip(self.exports, grads):
+            if g is None:
+                continue
+            tmp = ops.nchw_to_nhwc(g, self.dtype, C=var.act.C)
+            if var.relu_fused:                   # the buffer holds d/d(pre-ReLU): mask with the saved output
+                ops.relu_bwd(tmp, var.act, tmp)
+            ops.copy_slice(tmp, self.grad_of(var.act), accumulate=var.ready)
+            var.ready = True
 
     def input(self, x):
         """NCHW tensor -> NHWC activation Var (layout conversion by a torch copy: boundary plumbing)."""
@@ -303,7 +323,14 @@ class Runtime:
 
         def state(members):
             r = [m.ready for m in members]
-            assert all(r) or not any(r), "mixed gradient readiness inside one concat segment"
+            if any(r) and not all(r):
+                # some members already hold a gradient (an exported tensor's, from the caller): zero the others and add
+                assert self.exports, "mixed gradient readiness inside one concat segment"
+                for m in members:
+                    if not m.ready:
+                        self.grad_of(m.act).nchw().zero_()
+                        m.ready = True
+                return True
             return r[0]
 
         if len(segs) == 1:

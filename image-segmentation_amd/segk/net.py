@@ -45,23 +45,28 @@ class _TapeFn(torch.autograd.Function):
         else:
             plan = plans[key] = PackPlan()
         rt.pack_plan = plan
-        logits = net._emit(rt, x)
+        out = net._emit(rt, x)
         if not plan.ready:
             plan.finalize(x.device)
         rt.finish_forward(net)
         ctx.rt, ctx.names, ctx.hooks = rt, names, hooks
         ctx.set_materialize_grads(False)
-        return logits
+        if isinstance(out, tuple):               # (logits, feature maps made with rt.export)
+            return (out[0],) + tuple(out[1])
+        return out
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, *dfeats):
         rt = ctx.rt
-        if dlogits is None:
+        if dlogits is None and all(g is None for g in dfeats):
             return (None, None, None) + tuple(None for _ in ctx.names)
         begin, finish = ctx.hooks[2], ctx.hooks[3]
         if begin is not None:
             begin()
+        if dlogits is None:
+            dlogits = torch.zeros_like(rt._head[4])
         rt.head_backward(dlogits)
+        rt.import_gradients(dfeats)
         rt.backward()
         ctx.rt = None
         if finish is not None:
@@ -96,7 +101,13 @@ class SegkNet(nn.Module):
         self._segk_param_names = [n for n, _ in named]
         params = [p for _, p in named]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _TapeFn.apply(self, x, need_grad, *params)
+        out = _TapeFn.apply(self, x, need_grad, *params)
+        if isinstance(out, tuple):               # networks with extra outputs: (logits, feature maps) in the reference's nesting
+            return self._pack_outputs(out[0], list(out[1:]))
+        return out
+
+    def _pack_outputs(self, logits, feats):
+        return logits, feats
 
 
 class _BlockFn(torch.autograd.Function):

@@ -169,12 +169,27 @@ def model_cases(ref):
     ]
 
 
+FEATURE_WEIGHT = 0.05
+
+
+def split_outputs(out):
+    """model output -> (logits, list of extra feature maps): the multi-output U-Nets return (logits, tensor or list)."""
+    if not isinstance(out, tuple):
+        return out, []
+    return out[0], list(out[1]) if isinstance(out[1], (list, tuple)) else [out[1]]
+
+
 def run_step(model, x, t, losses):
+    """Loss of the step: the given losses on the logits, plus FEATURE_WEIGHT * mean(f^2) for every extra feature map a
+    multi-output network returns (so that gradients flow back through those outputs as well)."""
     model.train()
     model.zero_grad()
-    logits = model(x)
+    logits, feats = split_outputs(model(x))
     loss = sum(fn(logits, t) for fn in losses)
+    for f in feats:
+        loss = loss + FEATURE_WEIGHT * (f * f).mean()
     loss.backward()
+    run_step.feats = [f.detach() for f in feats]
     return logits.detach(), loss.detach()
 
 
@@ -189,8 +204,12 @@ def _model_fixture(name, mk_ref, mk_or, in_ch, n_cls, out, keys, pin, dice_ref, 
         assert va.shape == vb.shape and torch.equal(va, vb), (name, ka)
     keys[name] = {k: list(v.shape) for k, v in m_ref.state_dict().items()}
     la, lossa = run_step(m_ref, x, t, [dice_ref.dice_loss_sq, focal_ref.focal_loss_with_logits])
+    feats_a = run_step.feats
     lb, lossb = run_step(m_or, x, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
-    same = bits_equal(la, lb) and bits_equal(lossa, lossb)
+    same = bits_equal(la, lb) and bits_equal(lossa, lossb) and len(feats_a) == len(run_step.feats)
+    for i, (fa, fb) in enumerate(zip(feats_a, run_step.feats)):
+        same = same and bits_equal(fa, fb)
+        out[f"{name}/feat{i}_sub"] = fa[..., ::4, ::4].contiguous().numpy()
     for (ka, pa), (_, pb) in zip(m_ref.named_parameters(), m_or.named_parameters()):
         same = same and bits_equal(pa.grad, pb.grad)
     for (ka, ba), (_, bb) in zip(m_ref.named_buffers(), m_or.named_buffers()):
@@ -211,7 +230,7 @@ def _model_fixture(name, mk_ref, mk_or, in_ch, n_cls, out, keys, pin, dice_ref, 
     # eval-mode logits after the step (running statistics path)
     m_ref.eval()
     with torch.no_grad():
-        le = m_ref(x)
+        le, _ = split_outputs(m_ref(x))
     out[f"{name}/eval_logits_sub"] = le[..., ::4, ::4].contiguous().numpy()
     out[f"{name}/eval_mask"] = le.argmax(1).to(torch.uint8).numpy()
 
@@ -258,6 +277,11 @@ def variant_cases(ref):
          lambda: RM.RefUNetNaive(out_classes=3, in_classes=1, if_convtrans=True, ifmaxpool=True), 1),
         ("unetnocenter_c4", lambda: uv.UNetWithoutCenter(out_classes=4, in_classes=1),
          lambda: RM.RefUNetNaive(out_classes=4, in_classes=1, center=False), 1),
+        ("unetsimple_multi_cs32_c3", lambda: uv.UNetSimple(out_classes=3, in_classes=1, channelscale=32, multiout=True),
+         lambda: RM.RefUNetSimple(out_classes=3, in_classes=1, channelscale=32, multiout=True), 1),
+        ("unetnaivemulti_c4", lambda: uv.UNetNaiveMultiOut(out_classes=4, in_classes=1), lambda: RM.RefUNetFourLevel(out_classes=4), 1),
+        ("unetlimmulti_c4", lambda: uv.UNetLimMultiOut(out_classes=4, in_classes=1, multiout=True),
+         lambda: RM.RefUNetFourLevel(out_classes=4, channel_depth=16), 1),
     ]
 
 

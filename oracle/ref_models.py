@@ -5,7 +5,8 @@ Plain `torch.nn` restatement of the two graded networks with the reference's sta
 * VGG16-BN encoder + five-stage decoder -- /root/reference/models/unetvgg.py:6-41 (decoder block),
   :52-105 (UNetVgg), :158-213 (UNetVggInOut)
 * plain InstanceNorm U-Nets             -- /root/reference/models/unetvgg.py:268-323 (encoder block), :335-372 (center),
-                                           :373-440 (UNetNaive), :443-506 (UNetWithoutCenter), :651-728 (UNetSimple)
+                                           :373-440 (UNetNaive), :443-506 (UNetWithoutCenter), :509-574 (UNetNaiveMultiOut),
+                                           :576-648 (UNetLimMultiOut), :651-728 (UNetSimple)
 * nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
 * 3-D DenseNet-BC classifier + DetectMid -- /root/reference/models/densenet3d.py:10-159, 162-186;
                                            /root/reference/models/resnt.py:8-45
@@ -91,9 +92,9 @@ def encoder_block(c_in, c_mid, c_out, convs3=True, c_mid2=None, no_dsam=False):
 
 
 class RefUNetSimple(nn.Module):
-    def __init__(self, out_classes=3, in_classes=1, channelscale=64, noupdownsam=False):
+    def __init__(self, out_classes=3, in_classes=1, channelscale=64, noupdownsam=False, multiout=False):
         super().__init__()
-        cs, nd = channelscale, noupdownsam
+        cs, nd, self.multiout = channelscale, noupdownsam, multiout
         self.conv1 = nn.Sequential(nn.Conv2d(in_classes, cs, 3, padding=1, bias=False), nn.InstanceNorm2d(cs), nn.ReLU(inplace=True),
                                    nn.Conv2d(cs, cs, 3, padding=1, bias=False), nn.InstanceNorm2d(cs), nn.ReLU(inplace=True))
         self.conv2 = encoder_block(cs, 2 * cs, 2 * cs, convs3=False, no_dsam=nd)
@@ -114,10 +115,11 @@ class RefUNetSimple(nn.Module):
         c3 = self.conv3(c2)
         c4 = self.conv4(c3)
         c5 = self.conv5(c4)
-        d = self.dec4(torch.cat([c5, c4], 1))
-        d = self.dec3(torch.cat([d, c3], 1))
-        d = self.dec2(torch.cat([d, c2], 1))
-        return self.final(self.dec1(torch.cat([d, c1], 1)))
+        d4 = self.dec4(torch.cat([c5, c4], 1))
+        d3 = self.dec3(torch.cat([d4, c3], 1))
+        d2 = self.dec2(torch.cat([d3, c2], 1))
+        d1 = self.dec1(torch.cat([d2, c1], 1))
+        return (self.final(d1), [d1, d2, d3, d4]) if self.multiout else self.final(d1)
 
 
 def _in_stem(in_classes, wdt):
@@ -171,6 +173,45 @@ class RefUNetNaive(nn.Module):
         d = self.dec3(torch.cat([d, c3], 1))
         d = self.dec2(torch.cat([d, c2], 1))
         return self.final(self.dec1(torch.cat([d, c1], 1)))
+
+
+class RefUNetFourLevel(nn.Module):
+    """UNetNaiveMultiOut (unetvgg.py:509-574; widths 64..512, returns [conv3, dec4]) and UNetLimMultiOut (:576-648; every
+    layer `channel_depth` wide, returns conv3 when multiout): bias-free conv-IN-ReLU bottom stage."""
+
+    def __init__(self, out_classes=3, in_classes=1, channel_depth=None, multiout=True):
+        super().__init__()
+        lim = channel_depth is not None
+        self.lim, self.multiout = lim, multiout
+        e = [channel_depth] * 4 if lim else [64, 128, 256, 512]
+        bottom = channel_depth // 2 if lim else 256
+        dec_out = [channel_depth // 2] * 3 if lim else [256, 64, 32]          # dec4, dec3, dec2
+        dec_mid = [channel_depth] * 3 if lim else [512, 256, 128]
+        self.conv1 = _in_stem(in_classes, e[0])
+        self.conv2 = encoder_block(e[0], e[1], e[1], convs3=False)
+        self.conv3 = encoder_block(e[1], e[2], e[2], c_mid2=e[2])
+        self.conv4 = encoder_block(e[2], e[3], e[3], c_mid2=e[3])
+        self.conv5 = nn.Sequential(nn.Conv2d(e[3], e[3], 3, padding=1, bias=False), nn.InstanceNorm2d(e[3]), nn.ReLU(inplace=True),
+                                   nn.Conv2d(e[3], bottom, 3, padding=1, bias=False), nn.InstanceNorm2d(bottom), nn.ReLU(inplace=True))
+        self.dec4 = decoder_block(bottom + e[3], dec_mid[0], dec_out[0])
+        self.dec3 = decoder_block(dec_out[0] + e[2], dec_mid[1], dec_out[1])
+        self.dec2 = decoder_block(dec_out[1] + e[1], dec_mid[2], dec_out[2])
+        last = channel_depth if lim else 32
+        self.dec1 = nn.Sequential(nn.Conv2d(dec_out[2] + e[0], last, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(last, out_classes, 1)
+
+    def forward(self, x):
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c4 = self.conv4(c3)
+        d4 = self.dec4(torch.cat([self.conv5(c4), c4], 1))
+        d = self.dec3(torch.cat([d4, c3], 1))
+        d = self.dec2(torch.cat([d, c2], 1))
+        y = self.final(self.dec1(torch.cat([d, c1], 1)))
+        if not self.multiout:
+            return y
+        return (y, c3) if self.lim else (y, [c3, d4])
 
 
 class RefDoubleConv(nn.Module):

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import VARIANTS, input_channels, rel_l2, report, variant_oracle, variant_product
+from util import VARIANTS, input_channels, rel_l2, report, split_outputs, step_loss, variant_oracle, variant_product
 
 pytestmark = pytest.mark.gpu
 
@@ -42,11 +42,11 @@ def run_step(name, dtype, side=64, n=2, tag=None):
     model = model.cuda().train().set_compute_dtype(dtype)
     x, t = synthetic_batch(n, side, n_cls, in_ch=in_ch, tag=tag or f"model:{name}")
     before = _lib.launches
-    logits = model(x.cuda())
-    loss = dice_loss_sq(logits, t.cuda()) + focal_loss_with_logits(logits, t.cuda())
+    logits, feats, loss = step_loss(model(x.cuda()), t.cuda(), dice_loss_sq, focal_loss_with_logits)
     loss.backward()
     torch.cuda.synchronize()
     assert _lib.launches - before > 50, "the HIP library did not run the network"
+    run_step.feats = [f.detach() for f in feats]
     return model, logits.detach(), loss.detach()
 
 
@@ -67,10 +67,9 @@ def oracle_step(name, dtype, side=64, n=2, tag=None, autocast=False):
     m = RM.hash_init_(mk()).to(dtype).train()
     if autocast:
         with torch.autocast("cpu", dtype=torch.bfloat16):
-            logits = m(x)
+            logits, _ = split_outputs(m(x))
         return m, logits.detach().float(), None
-    logits = m(x.to(dtype))
-    loss = RL.dice_loss_sq(logits, t) + RL.focal_loss_with_logits(logits, t)
+    logits, _, loss = step_loss(m(x.to(dtype)), t, RL.dice_loss_sq, RL.focal_loss_with_logits)
     loss.backward()
     return m, logits.detach(), loss.detach()
 
@@ -109,6 +108,8 @@ def test_fp32_step_vs_golden(name, golden):
     want = torch.from_numpy(g[f"{name}/logits"])
     report(f"{name}/logits", logits.cpu(), want, rtol=1e-4, atol=1e-4)
     report(f"{name}/loss", loss.cpu(), torch.from_numpy(g[f"{name}/loss"]), rtol=1e-4, atol=1e-6)
+    for i, f in enumerate(run_step.feats):       # extra outputs of the multi-output networks
+        report(f"{name}/feat{i}", f[..., ::4, ::4].cpu(), torch.from_numpy(g[f"{name}/feat{i}_sub"]), rtol=1e-4, atol=1e-4)
     # arg-max masks: bit-exact wherever the reference's top-2 margin exceeds the logit tolerance
     top2 = want.topk(2, dim=1).values
     safe = (top2[:, 0] - top2[:, 1]) > 4e-4
@@ -133,7 +134,7 @@ def test_fp32_step_vs_golden(name, golden):
     from oracle.ref_models import synthetic_batch
     x, _ = synthetic_batch(2, 64, 3 if name.endswith("c3") else 4, in_ch=input_channels(name), tag=f"model:{name}")
     with torch.no_grad():
-        le = model(x.cuda())
+        le, _ = split_outputs(model(x.cuda()))
     report(f"{name}/eval_logits", le[..., ::4, ::4].cpu(), torch.from_numpy(g[f"{name}/eval_logits_sub"]), rtol=1e-4, atol=1e-4)
 
 

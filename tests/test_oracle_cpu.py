@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import VARIANTS, input_channels, report, variant_oracle, variant_product
+from util import VARIANTS, input_channels, report, step_loss, variant_oracle, variant_product
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -169,7 +169,8 @@ def test_state_dict_layout_matches_reference(name):
     _product(name).load_state_dict(_oracle(name).state_dict(), strict=True)
 
 
-@pytest.mark.parametrize("name", ["unetvgg_c4", "nestedunet_c4", "unetsimple_cs32_c3", "unetnaive_convtrans_pool_c3"])
+@pytest.mark.parametrize("name", ["unetvgg_c4", "nestedunet_c4", "unetsimple_cs32_c3", "unetnaive_convtrans_pool_c3", "unetlimmulti_c4",
+                                  "unetsimple_multi_cs32_c3"])
 def test_oracle_and_host_path_match_golden(name, golden):
     """One train step on CPU: the oracle equals the golden vectors bit for bit, and the product's CPU-tensor
     path (plain torch.nn modules holding the same parameters) equals the oracle."""
@@ -182,15 +183,16 @@ def test_oracle_and_host_path_match_golden(name, golden):
     x, t = synthetic_batch(2, 64, 3 if name.endswith("c3") else 4, in_ch=in_ch, tag=f"model:{name}")
     torch.set_num_threads(8)
     m = hash_init_(_oracle(name)).train()
-    logits = m(x)
-    loss = RL.dice_loss_sq(logits, t) + RL.focal_loss_with_logits(logits, t)
+    logits, feats, loss = step_loss(m(x), t, RL.dice_loss_sq, RL.focal_loss_with_logits)
     loss.backward()
+    for i, f in enumerate(feats):
+        assert np.array_equal(f.detach()[..., ::4, ::4].numpy(), g[f"{name}/feat{i}_sub"])
     assert np.array_equal(logits.detach().numpy(), g[f"{name}/logits"])
     assert np.array_equal(loss.detach().numpy(), g[f"{name}/loss"])
     assert np.array_equal(logits.argmax(1).to(torch.uint8).numpy(), g[f"{name}/mask"])
     p = hash_init_(_product(name)).train()
-    lp = p(x)
-    lossp = dice_loss_sq(lp, t) + focal_loss_with_logits(lp, t)
+    lp, featsp, lossp = step_loss(p(x), t, dice_loss_sq, focal_loss_with_logits)
+    assert len(featsp) == len(feats)
     lossp.backward()
     report("host logits", lp, logits, rtol=1e-5, atol=1e-5)
     report("host loss", lossp, loss, rtol=1e-5, atol=1e-6)
@@ -241,6 +243,9 @@ def test_constructor_surface():
     assert [type(c).__name__ for c in enc] == ["Conv2d"] + ["Conv2d", "InstanceNorm2d", "ReLU"] * 3 and enc[0].stride == (2, 2)
     assert len(make_encoder_block(8, 16, 16, convs3=False, max_pool=True)) == 7
     assert enc(torch.zeros(1, 8, 8, 8)).shape == (1, 16, 4, 4)
+    from models.unetvgg import UNetLimMultiOut, UNetNaiveMultiOut
+    assert torch.is_tensor(UNetLimMultiOut(multiout=True)(torch.zeros(1, 1, 16, 16))[1])
+    assert [f.shape[1] for f in UNetNaiveMultiOut()(torch.zeros(1, 1, 16, 16))[1]] == [256, 256]
     u = UNetSimple(channelscale=16, multiout=True)
     out, feats = u(torch.zeros(1, 1, 16, 16))
     assert out.shape == (1, 3, 16, 16) and [f.shape[1] for f in feats] == [8, 8, 16, 64]

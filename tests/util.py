@@ -38,7 +38,29 @@ VARIANTS = {
     "unetnaive_convtrans_pool_c3": ("UNetNaive", dict(out_classes=3, in_classes=1, if_convtrans=True, ifmaxpool=True),
                                     "RefUNetNaive", dict(out_classes=3, if_convtrans=True, ifmaxpool=True)),
     "unetnocenter_c4": ("UNetWithoutCenter", dict(out_classes=4, in_classes=1), "RefUNetNaive", dict(out_classes=4, center=False)),
+    # networks that also return feature maps (their loss adds FEATURE_WEIGHT * mean(f^2) per map, see step_loss)
+    "unetsimple_multi_cs32_c3": ("UNetSimple", dict(out_classes=3, in_classes=1, channelscale=32, multiout=True),
+                                 "RefUNetSimple", dict(out_classes=3, channelscale=32, multiout=True)),
+    "unetnaivemulti_c4": ("UNetNaiveMultiOut", dict(out_classes=4, in_classes=1), "RefUNetFourLevel", dict(out_classes=4)),
+    "unetlimmulti_c4": ("UNetLimMultiOut", dict(out_classes=4, in_classes=1, multiout=True), "RefUNetFourLevel", dict(out_classes=4, channel_depth=16)),
 }
+FEATURE_WEIGHT = 0.05
+
+
+def split_outputs(out):
+    """model output -> (logits, list of extra feature maps)."""
+    if not isinstance(out, tuple):
+        return out, []
+    return out[0], list(out[1]) if isinstance(out[1], (list, tuple)) else [out[1]]
+
+
+def step_loss(out, t, dice, focal):
+    """The loss the fixtures were generated with: Dice + focal on the logits, plus FEATURE_WEIGHT * mean(f^2) per extra map."""
+    logits, feats = split_outputs(out)
+    loss = dice(logits, t) + focal(logits, t)
+    for f in feats:
+        loss = loss + FEATURE_WEIGHT * (f * f).mean()
+    return logits, feats, loss
 
 
 def variant_product(name):
