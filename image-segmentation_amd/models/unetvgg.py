@@ -3,7 +3,8 @@
 Same constructor signatures, attribute names and state_dict layout as the reference classes
 (/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213,
 make_encoder_block :268-323, make_center :335-372, UNetNaive :373-440, UNetWithoutCenter :443-506,
-UNetNaiveMultiOut :509-574, UNetLimMultiOut :576-648, UNetSimple :651-728),
+UNetNaiveMultiOut :509-574, UNetLimMultiOut :576-648, UNetSimple :651-728, UNetSkip :730-813,
+UNetSimpleReduced :815-894),
 so checkpoints and callers are interchangeable.  The module tree is made of ordinary torch.nn layers
 that only hold the parameters (and serve CPU tensors); for CUDA tensors `forward` hands the
 parameters to the segk tape (segk/engine.py), which launches the HIP kernels: implicit-GEMM
@@ -446,6 +447,7 @@ class UNetLimMultiOut(SegkNet):
 class UNetSimple(SegkNet):
     """Four-level U-Net with InstanceNorm and learned stride-2 down-sampling (reference :651-728); `pretrained` is
     accepted and unused, as there."""
+    _export_names = ("d1", "d2", "d3", "d4")         # multiout: [dec1, dec2, dec3, dec4] (reference :726)
 
     def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1, channelscale=64, multiout=False,
                  noupdownsam=False):
@@ -506,4 +508,79 @@ class UNetSimple(SegkNet):
         d2 = self.dec2.emit(rt, "dec2.", [d3, c2], out=Act(cat1, 0, cs // 2))
         e = rt.conv([d2, c1], "dec1.0.weight", "dec1.0.bias", relu=True)
         logits = rt.head(e, "final.weight", "final.bias")
-        return (logits, [rt.export(v) for v in (e, d2, d3, d4)]) if self.multiout else logits
+        tensors = {"d1": e, "d2": d2, "d3": d3, "d4": d4}
+        return (logits, [rt.export(tensors[k]) for k in self._export_names]) if self.multiout else logits
+
+
+class UNetSkip(UNetSimple):
+    """UNetSimple with channelscale 32 by default; with multiout it returns (logits, dec4) (reference :730-813).  The
+    reference also resizes three crops of the input (:795,:804,:807) and never uses them; that dead work is left out."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1, channelscale=32, multiout=False,
+                 noupdownsam=False):
+        super().__init__(pretrained=pretrained, out_classes=out_classes, patch_train=patch_train, in_classes=in_classes,
+                         channelscale=channelscale, multiout=multiout, noupdownsam=noupdownsam)
+        self.xcontr = 3
+
+    def _forward_host(self, x):
+        out = super()._forward_host(x)
+        return (out[0], out[1][3]) if self.multiout else out
+
+    _export_names = ("d4",)
+
+    def _pack_outputs(self, logits, feats):
+        return logits, feats[0]
+
+
+class UNetSimpleReduced(SegkNet):
+    """UNetSimple without its two deepest stages (reference :815-894).  multiout=True names tensors that do not exist in
+    the reference's forward (:892) and raises there; it raises here as well."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1, channelscale=64, multiout=False,
+                 noupdownsam=False):
+        super().__init__()
+        cs = channelscale
+        self.multiout, self.patch_train, self.channelscale, self.noupdownsam = multiout, patch_train, cs, noupdownsam
+        self.conv1 = _stem_modules(in_classes, cs)
+        self.conv2 = make_encoder_block(cs, 2 * cs, 2 * cs, convs3=False, no_dsam=noupdownsam)
+        self.conv3 = make_encoder_block(2 * cs, 4 * cs, 8 * cs, middle_channels2=4 * cs, no_dsam=noupdownsam)
+        self.dec4 = make_decoder_block(8 * cs, 8 * cs, 4 * cs, noupsam=True)
+        self.dec3 = make_decoder_block(12 * cs, 4 * cs, cs, noupsam=noupdownsam)
+        self.dec2 = make_decoder_block(3 * cs, 2 * cs, cs // 2, noupsam=noupdownsam)
+        self.dec1 = nn.Sequential(nn.Conv2d(int(1.5 * cs), cs // 2, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(cs // 2, out_classes, kernel_size=1)
+
+    def _check(self):
+        if self.multiout:
+            raise NameError("name 'conv4' is not defined")       # what the reference's forward does at :892
+
+    def _forward_host(self, x):
+        conv1 = self.conv1(x)
+        conv2 = self.conv2(conv1)
+        conv3 = self.conv3(conv2)
+        dec3 = self.dec3(torch.cat([self.dec4(conv3), conv3], 1))
+        dec2 = self.dec2(torch.cat([dec3, conv2], 1))
+        out = self.final(self.dec1(torch.cat([dec2, conv1], 1)))
+        self._check()
+        return out
+
+    def _emit(self, rt, x):
+        self._check()
+        N, _, H, W = x.shape
+        cs, down = self.channelscale, not self.noupdownsam
+        if cs % 16:
+            raise NotImplementedError("channelscale must be a multiple of 16 (8-channel storage groups)")
+        if down and (H % 4 or W % 4):
+            raise RuntimeError(f"UNetSimpleReduced needs H and W divisible by 4 (two stride-2 convolutions), got {H}x{W}")
+
+        def level(k, C):
+            return rt.new(N, H >> k if down else H, W >> k if down else W, C).buf
+        cat1, cat2, cat3 = level(0, cs // 2 + cs), level(1, cs + 2 * cs), level(2, 4 * cs + 8 * cs)
+        c1 = _emit_stem(rt, x, Act(cat1, cs // 2, cs))
+        c2 = self.conv2.emit(rt, "conv2.", c1, out=Act(cat2, cs, 2 * cs))
+        c3 = self.conv3.emit(rt, "conv3.", c2, out=Act(cat3, 4 * cs, 8 * cs))
+        d4 = self.dec4.emit(rt, "dec4.", c3, out=Act(cat3, 0, 4 * cs))
+        d3 = self.dec3.emit(rt, "dec3.", [d4, c3], out=Act(cat2, 0, cs))
+        d2 = self.dec2.emit(rt, "dec2.", [d3, c2], out=Act(cat1, 0, cs // 2))
+        e = rt.conv([d2, c1], "dec1.0.weight", "dec1.0.bias", relu=True)
+        return rt.head(e, "final.weight", "final.bias")

@@ -282,6 +282,10 @@ def variant_cases(ref):
         ("unetnaivemulti_c4", lambda: uv.UNetNaiveMultiOut(out_classes=4, in_classes=1), lambda: RM.RefUNetFourLevel(out_classes=4), 1),
         ("unetlimmulti_c4", lambda: uv.UNetLimMultiOut(out_classes=4, in_classes=1, multiout=True),
          lambda: RM.RefUNetFourLevel(out_classes=4, channel_depth=16), 1),
+        ("unetskip_multi_c4", lambda: uv.UNetSkip(out_classes=4, in_classes=1, multiout=True),
+         lambda: RM.RefUNetSimple(out_classes=4, in_classes=1, channelscale=32, multiout="dec4"), 1),
+        ("unetsimplereduced_cs32_c3", lambda: uv.UNetSimpleReduced(out_classes=3, in_classes=1, channelscale=32),
+         lambda: RM.RefUNetSimpleReduced(out_classes=3, in_classes=1, channelscale=32), 1),
     ]
 
 

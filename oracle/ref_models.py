@@ -6,7 +6,8 @@ Plain `torch.nn` restatement of the two graded networks with the reference's sta
   :52-105 (UNetVgg), :158-213 (UNetVggInOut)
 * plain InstanceNorm U-Nets             -- /root/reference/models/unetvgg.py:268-323 (encoder block), :335-372 (center),
                                            :373-440 (UNetNaive), :443-506 (UNetWithoutCenter), :509-574 (UNetNaiveMultiOut),
-                                           :576-648 (UNetLimMultiOut), :651-728 (UNetSimple)
+                                           :576-648 (UNetLimMultiOut), :651-728 (UNetSimple), :730-813 (UNetSkip),
+                                           :815-894 (UNetSimpleReduced)
 * nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
 * 3-D DenseNet-BC classifier + DetectMid -- /root/reference/models/densenet3d.py:10-159, 162-186;
                                            /root/reference/models/resnt.py:8-45
@@ -119,6 +120,8 @@ class RefUNetSimple(nn.Module):
         d3 = self.dec3(torch.cat([d4, c3], 1))
         d2 = self.dec2(torch.cat([d3, c2], 1))
         d1 = self.dec1(torch.cat([d2, c1], 1))
+        if self.multiout == "dec4":             # UNetSkip (unetvgg.py:730-813): UNetSimple that returns (logits, dec4)
+            return self.final(d1), d4
         return (self.final(d1), [d1, d2, d3, d4]) if self.multiout else self.final(d1)
 
 
@@ -212,6 +215,30 @@ class RefUNetFourLevel(nn.Module):
         if not self.multiout:
             return y
         return (y, c3) if self.lim else (y, [c3, d4])
+
+
+class RefUNetSimpleReduced(nn.Module):
+    """unetvgg.py:815-894 (multiout=False)."""
+
+    def __init__(self, out_classes=3, in_classes=1, channelscale=64, noupdownsam=False):
+        super().__init__()
+        cs, nd = channelscale, noupdownsam
+        self.conv1 = _in_stem(in_classes, cs)
+        self.conv2 = encoder_block(cs, 2 * cs, 2 * cs, convs3=False, no_dsam=nd)
+        self.conv3 = encoder_block(2 * cs, 4 * cs, 8 * cs, c_mid2=4 * cs, no_dsam=nd)
+        self.dec4 = decoder_block(8 * cs, 8 * cs, 4 * cs, noupsam=True)
+        self.dec3 = decoder_block(12 * cs, 4 * cs, cs, noupsam=nd)
+        self.dec2 = decoder_block(3 * cs, 2 * cs, cs // 2, noupsam=nd)
+        self.dec1 = nn.Sequential(nn.Conv2d(cs + cs // 2, cs // 2, 3, padding=1), nn.ReLU(inplace=True))
+        self.final = nn.Conv2d(cs // 2, out_classes, 1)
+
+    def forward(self, x):
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        d = self.dec3(torch.cat([self.dec4(c3), c3], 1))
+        d = self.dec2(torch.cat([d, c2], 1))
+        return self.final(self.dec1(torch.cat([d, c1], 1)))
 
 
 class RefDoubleConv(nn.Module):

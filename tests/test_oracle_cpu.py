@@ -246,6 +246,10 @@ def test_constructor_surface():
     from models.unetvgg import UNetLimMultiOut, UNetNaiveMultiOut
     assert torch.is_tensor(UNetLimMultiOut(multiout=True)(torch.zeros(1, 1, 16, 16))[1])
     assert [f.shape[1] for f in UNetNaiveMultiOut()(torch.zeros(1, 1, 16, 16))[1]] == [256, 256]
+    from models.unetvgg import UNetSimpleReduced, UNetSkip
+    assert UNetSkip().channelscale == 32 and torch.is_tensor(UNetSkip(multiout=True)(torch.zeros(1, 1, 16, 16))[1])
+    with pytest.raises(NameError):
+        UNetSimpleReduced(channelscale=16, multiout=True)(torch.zeros(1, 1, 16, 16))
     u = UNetSimple(channelscale=16, multiout=True)
     out, feats = u(torch.zeros(1, 1, 16, 16))
     assert out.shape == (1, 3, 16, 16) and [f.shape[1] for f in feats] == [8, 8, 16, 64]

@@ -43,6 +43,8 @@ VARIANTS = {
                                  "RefUNetSimple", dict(out_classes=3, channelscale=32, multiout=True)),
     "unetnaivemulti_c4": ("UNetNaiveMultiOut", dict(out_classes=4, in_classes=1), "RefUNetFourLevel", dict(out_classes=4)),
     "unetlimmulti_c4": ("UNetLimMultiOut", dict(out_classes=4, in_classes=1, multiout=True), "RefUNetFourLevel", dict(out_classes=4, channel_depth=16)),
+    "unetskip_multi_c4": ("UNetSkip", dict(out_classes=4, in_classes=1, multiout=True), "RefUNetSimple", dict(out_classes=4, channelscale=32, multiout="dec4")),
+    "unetsimplereduced_cs32_c3": ("UNetSimpleReduced", dict(out_classes=3, in_classes=1, channelscale=32), "RefUNetSimpleReduced", dict(out_classes=3, channelscale=32)),
 }
 FEATURE_WEIGHT = 0.05
 
