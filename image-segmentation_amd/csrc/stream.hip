@@ -711,6 +711,102 @@ __global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const T* __restr
     Elem<T>::store8(dx + ((n * H + h) * W + w) * ld_dx + v * 8, acc);
 }
 
+// ------------------------------------------------------------------------------ bilinear resize by any factor
+// align_corners=False with an explicit scale factor: ATen maps output index o to the source coordinate
+// max(ratio * (o + 0.5) - 0.5, 0) with ratio = 1 / scale_factor (upsample_bilinear2d), taps i0 = floor, i1 = min(i0 + 1, in - 1).
+__device__ __forceinline__ Lerp lerp_taps_ratio(int o, int in, float ratio) {
+    float src = ratio * ((float)o + 0.5f) - 0.5f;
+    if (src < 0.f) src = 0.f;
+    Lerp l;
+    l.i0 = (int)src;
+    if (l.i0 > in - 1) l.i0 = in - 1;
+    l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.f - l.w1;
+    return l;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void resize_fwd_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C, int Ho, int Wo,
+                                                              float rh, float rw, const float* __restrict__ stats, int relu,
+                                                              T* __restrict__ y, int64_t ldy) {
+    const int cv = C / 8;
+    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, Ho, Wo, cv);   // one OUTPUT pixel (8 channels) per thread
+    if (!it.ok) return;
+    const int oy = it.h, ox = it.w, v = it.v;
+    const int64_t n = it.n;
+    const Lerp ly = lerp_taps_ratio(oy, H, rh), lx = lerp_taps_ratio(ox, W, rw);
+    const T* b = x + n * H * W * ldx + v * 8;
+    float a00[8], a01[8], a10[8], a11[8], o[8];
+    Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i0) * ldx, a00);
+    Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i1) * ldx, a01);
+    Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i0) * ldx, a10);
+    Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i1) * ldx, a11);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float val = ly.w0 * (lx.w0 * a00[j] + lx.w1 * a01[j]) + ly.w1 * (lx.w0 * a10[j] + lx.w1 * a11[j]);
+        if (stats) {
+            const int c = v * 8 + j;
+            val = (val - stats[(n * C + c) * 2]) * stats[(n * C + c) * 2 + 1];
+        }
+        o[j] = relu ? fmaxf(val, 0.f) : val;
+    }
+    Elem<T>::store8(y + ((n * Ho + oy) * Wo + ox) * ldy + v * 8, o);
+}
+
+// Adjoint in gather form (deterministic): input index h is a tap of the outputs whose source coordinate lies in
+// (h - 1, h + 1), i.e. o in ((h - 0.5) / ratio - 0.5, (h + 1.5) / ratio - 0.5); the clamped first and last outputs are
+// covered by widening that window by one on both sides and testing every candidate's taps.
+__device__ __forceinline__ void resize_window(int h, int out, float ratio, int& lo, int& hi) {
+    lo = (int)floorf(((float)h - 0.5f) / ratio - 0.5f) - 1;
+    hi = (int)ceilf(((float)h + 1.5f) / ratio - 0.5f) + 1;
+    if (lo < 0) lo = 0;
+    if (hi > out - 1) hi = out - 1;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void resize_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy, int H, int W, int C, int Ho, int Wo,
+                                                              float rh, float rw, T* __restrict__ dx, int64_t ld_dx, int accumulate) {
+    const int cv = C / 8;
+    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, H, W, cv);     // one INPUT pixel (8 channels) per thread
+    if (!it.ok) return;
+    const int h = it.h, w = it.w, v = it.v;
+    const int64_t n = it.n;
+    int ylo, yhi, xlo, xhi;
+    resize_window(h, Ho, rh, ylo, yhi);
+    resize_window(w, Wo, rw, xlo, xhi);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        const Lerp l = lerp_taps_ratio(oy, H, rh);
+        const float wy = (l.i0 == h ? l.w0 : 0.f) + (l.i1 == h ? l.w1 : 0.f);
+        if (wy == 0.f) continue;
+        float row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            const Lerp m = lerp_taps_ratio(ox, W, rw);
+            const float wx = (m.i0 == w ? m.w0 : 0.f) + (m.i1 == w ? m.w1 : 0.f);
+            if (wx == 0.f) continue;
+            float d[8];
+            Elem<T>::load8(dy + ((n * Ho + oy) * Wo + ox) * ld_dy + v * 8, d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) row[j] += wx * d[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy * row[j];
+    }
+    T* dst = dx + ((n * H + h) * W + w) * ld_dx + v * 8;
+    if (accumulate) {
+        float o[8];
+        Elem<T>::load8(dst, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += o[j];
+    }
+    Elem<T>::store8(dst, acc);
+}
+
 // Fast paths for align_corners=False (the decoder blocks): with scale 2 the taps are fixed.  Output rows 2h and
 // 2h+1 read input rows (h-1, h) and (h, h+1) with weights (0.25, 0.75) and (0.75, 0.25); output 0 puts all its
 // weight on input 0, and past the last row the clamped neighbour is the row itself.  One thread owns one INPUT
@@ -1338,6 +1434,34 @@ extern "C" int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, con
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, (int)H, (int)W, (int)C,
                                                      flags & 1, (flags >> 2) & 1, (T*)dx, ld_dx));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_resize_bilinear_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C, int64_t Ho,
+                                        int64_t Wo, float ratio_h, float ratio_w, const float* stats, int flags, void* y, int64_t ldy,
+                                        int dev, void* stream) {
+    SEGK_CHECK_ACT("resize_fwd(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("resize_fwd(y)", y, ldy, C, dtype);
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && ratio_h > 0.f && ratio_w > 0.f, SEGK_ESHAPE, "resize_fwd: bad shape");
+    SEGK_HIP(use_device(dev));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resize_fwd_kernel<T>), dim3((unsigned)patch_blocks(N, Ho, Wo, C)), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)x, ldx, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, ratio_h,
+                                                     ratio_w, stats, flags & 1, (T*)y, ldy));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_resize_bilinear_bwd(int dtype, const void* dy, int64_t ld_dy, int64_t N, int64_t H, int64_t W, int64_t C, int64_t Ho,
+                                        int64_t Wo, float ratio_h, float ratio_w, void* dx, int64_t ld_dx, int flags, int dev,
+                                        void* stream) {
+    SEGK_CHECK_ACT("resize_bwd(dy)", dy, ld_dy, C, dtype);
+    SEGK_CHECK_ACT("resize_bwd(dx)", dx, ld_dx, C, dtype);
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && ratio_h > 0.f && ratio_w > 0.f, SEGK_ESHAPE, "resize_bwd: bad shape");
+    SEGK_HIP(use_device(dev));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resize_bwd_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
+                                                     (hipStream_t)stream, (const T*)dy, ld_dy, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, ratio_h,
+                                                     ratio_w, (T*)dx, ld_dx, (flags >> 1) & 1));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

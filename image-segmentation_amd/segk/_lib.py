@@ -82,6 +82,8 @@ _PROTOS = {
     "segk_colsum": (I, [I, P, L, L, L, P, I, P, Z, I, P]),
     "segk_copy_slice": (I, [I, P, L, P, L, L, L, I, I, P]),
     "segk_block2": (I, [I, P, L, P, L, L, L, L, L, I, I, P]),
+    "segk_resize_bilinear_fwd": (I, [I, P, L, L, L, L, L, L, L, F, F, P, I, P, L, I, P]),
+    "segk_resize_bilinear_bwd": (I, [I, P, L, L, L, L, L, L, L, F, F, P, L, I, I, P]),
     "segk_adam_step": (I, [P, P, P, P, L, F, F, F, F, F, L, F, I, P]),
 }
 

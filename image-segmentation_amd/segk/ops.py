@@ -356,6 +356,22 @@ def upsample_bwd(dy, y, dx, relu=False, align=False):
     return dx
 
 
+def resize_fwd(x, out, scale, stats=None, relu=False):
+    """Bilinear resize of x into out (its size fixes Ho, Wo) as nn.Upsample(scale_factor=scale, align_corners=False)."""
+    dev, st = _env(x.buf)
+    call("segk_resize_bilinear_fwd", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, out.H, out.W, 1.0 / scale, 1.0 / scale, _p(stats),
+         RELU if relu else 0, out.ptr, out.ld, dev, st)
+    return out
+
+
+def resize_bwd(dy, dx, scale, accumulate=False):
+    """dx (low- or high-resolution input shape) (+)= adjoint of resize_fwd applied to dy."""
+    dev, st = _env(dy.buf)
+    call("segk_resize_bilinear_bwd", dt(dy.dtype), dy.ptr, dy.ld, dx.N, dx.H, dx.W, dx.C, dy.H, dy.W, 1.0 / scale, 1.0 / scale,
+         dx.ptr, dx.ld, ACCUM if accumulate else 0, dev, st)
+    return dx
+
+
 def colsum(x, out, accumulate=False):
     dev, st = _env(x.buf)
     ws = workspace(query("segk_colsum_workspace", x.P, x.C), x.device)

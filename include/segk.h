@@ -364,6 +364,18 @@ int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int64_t C, floa
 int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t P,
                     int64_t C, int flags, int dev, void* stream);
 
+/* Bilinear resize by any factor, align_corners=False: y[n, Ho x Wo, c] = act((bilinear(x) - mean) * rstd), source coordinate
+ * max(ratio * (o + 0.5) - 0.5, 0) with ratio = 1 / scale_factor as ATen forms it; stats NULL means no normalisation.
+ * flags bit0: ReLU.   _bwd: dx (+)= adjoint of the interpolation applied to dy (gather form, deterministic); flags bit1: dx += .
+ * replaces: InstanceNorm2d + nn.Upsample(scale_factor=upsc, mode='bilinear') + ReLU of make_decoder_block for upsc other
+ * than 2 (models/unetvgg.py:36, used with upsc = 8, 4, 0.5 by SpiderNet :955-960).                    */
+int segk_resize_bilinear_fwd(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
+                             int64_t Ho, int64_t Wo, float ratio_h, float ratio_w, const float* stats, int flags,
+                             void* y, int64_t ldy, int dev, void* stream);
+int segk_resize_bilinear_bwd(int dtype, const void* dy, int64_t ld_dy, int64_t N, int64_t H, int64_t W, int64_t C,
+                             int64_t Ho, int64_t Wo, float ratio_h, float ratio_w, void* dx, int64_t ld_dx, int flags,
+                             int dev, void* stream);
+
 /* 2x2 pixel blocks <-> channels: wide[n,oh,ow,(b*2+e)*C + c] = x[n,2*oh+b,2*ow+e,c] ([N,H,W,C] -> [N,H/2,W/2,4C]).
  * With the weight read as [Cout][(b,e,c)] a Conv2d(kernel_size=2, stride=2) becomes a 1x1 convolution over
  * `wide` (segk_conv_fwd with taps = 1).  flags bit0: run backwards (x from wide: the data gradient);

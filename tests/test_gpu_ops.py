@@ -481,3 +481,33 @@ def test_strided_2x2_convolution(dtype):
     report("down2_dw", rt.grads["w"].cpu(), wd.grad, rtol=TOL[dtype]["rtol"], atol=1e-3 if dtype == torch.float32 else 5e-2)
     report("down2_db", rt.grads["b"].cpu(), bd.grad, rtol=1e-4, atol=1e-3)
     rt.release()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("scale", [8, 4, 0.5, 0.25])
+def test_bilinear_resize_any_factor(dtype, scale):
+    """nn.Upsample(scale_factor=s, mode='bilinear', align_corners=False) for s other than 2 (models/unetvgg.py:36 with
+    upsc = 8, 4, 0.5): forward (also with fused InstanceNorm + ReLU) and the adjoint against torch."""
+    from segk import ops
+    N, C, H, W = 2, 16, 6 if scale >= 1 else 16, 10 if scale >= 1 else 24
+    x = rnd((N, C, H, W), dtype, 91)
+    Ho, Wo = int(H * scale), int(W * scale)
+    dy = rnd((N, C, Ho, Wo), dtype, 92)
+    xa = to_act(x, dtype, ld=32, c0=8)
+    xd = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(xd, scale_factor=scale, mode="bilinear", align_corners=False)
+    ref.backward(dy)
+    out = ops.resize_fwd(xa, ops.Act.empty(N, Ho, Wo, C, dtype, "cuda"), scale)
+    report(f"resize_x{scale}", from_act(out), ref.detach(), **TOL[dtype])
+    dx = ops.Act(torch.ones(N, H, W, 32, device="cuda", dtype=dtype), 8, C)
+    ops.resize_bwd(to_act(dy, dtype), dx, scale)
+    report(f"resize_x{scale}_dx", from_act(dx), xd.grad, **TOL[dtype])
+    ops.resize_bwd(to_act(dy, dtype), dx, scale, accumulate=True)
+    report(f"resize_x{scale}_dx_accum", from_act(dx), 2 * xd.grad, rtol=2 * TOL[dtype]["rtol"], atol=2 * TOL[dtype]["atol"])
+    assert float(dx.buf[..., :8].sub(1).abs().max()) == 0
+    # fused InstanceNorm (statistics of the low-resolution input) + ReLU
+    stats = torch.empty(2 * N * C, device="cuda")
+    ops.norm_stats(xa, N, 1e-5, stats)
+    fused = ops.resize_fwd(xa, ops.Act.empty(N, Ho, Wo, C, dtype, "cuda"), scale, stats=stats, relu=True)
+    want = torch.relu(torch.nn.functional.interpolate(torch.nn.functional.instance_norm(x), scale_factor=scale, mode="bilinear", align_corners=False))
+    report(f"in_resize_x{scale}_relu", from_act(fused), want, **TOL[dtype])
