@@ -4,7 +4,7 @@ Same constructor signatures, attribute names and state_dict layout as the refere
 (/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213,
 make_encoder_block :268-323, make_center :335-372, UNetNaive :373-440, UNetWithoutCenter :443-506,
 UNetNaiveMultiOut :509-574, UNetLimMultiOut :576-648, UNetSimple :651-728, UNetSkip :730-813,
-UNetSimpleReduced :815-894),
+UNetSimpleReduced :815-894, SpiderNet :896-993),
 so checkpoints and callers are interchangeable.  The module tree is made of ordinary torch.nn layers
 that only hold the parameters (and serve CPU tensors); for CUDA tensors `forward` hands the
 parameters to the segk tape (segk/engine.py), which launches the HIP kernels: implicit-GEMM
@@ -14,6 +14,7 @@ skip concatenations of :99-103 written in place into shared NHWC buffers.
 from collections import OrderedDict
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from segk.engine import Var
@@ -58,10 +59,8 @@ class DecoderBlock(SegkBlock, nn.Sequential):
         h = rt.conv(x, prefix + "0.weight", prefix + "0.bias", relu=True)
         if self.kind == "convtrans":
             return rt.conv_transpose_relu(h, prefix + "2.weight", prefix + "2.bias", out=out)
-        if self.kind == "bilinear" and self.upsc != 2:
-            raise NotImplementedError("the HIP up-sampling stream is specialised for scale factor 2")
         y = rt.conv(h, prefix + "2.weight", stats="instance")
-        return rt.in_up_relu(y, out=out, upsample=self.kind == "bilinear")
+        return rt.in_up_relu(y, out=out, upsample=self.kind == "bilinear", scale=self.upsc)
 
 
 def make_decoder_block(in_channels, middle_channels, out_channels, if_convtrans=False, noupsam=False, upsc=2):
@@ -188,7 +187,7 @@ class EncoderBlock(nn.Sequential):
             layers += [nn.Conv2d(c, width, 3, padding=1, bias=False), nn.InstanceNorm2d(width), nn.ReLU(inplace=True)]
             c = width
         super().__init__(*layers)
-        self.kind, self.groups = kind, len(widths)
+        self.kind, self.groups, self.downsc = kind, len(widths), downsc
 
     def emit(self, rt, prefix, x, out=None):
         """Append this block to a segk tape; the last group writes into `out` (a slice of a concat buffer)."""
@@ -199,9 +198,15 @@ class EncoderBlock(nn.Sequential):
         elif self.kind == "pool":
             h = rt.pool(x)
         else:
-            raise NotImplementedError("bilinear re-scaling of the encoder input has no HIP kernel (scale factor 2 up-sampling only)")
+            # SpiderNet's branches (reference :925-941) re-scale the network INPUT: `x` is the NCHW image here.  Resizing a
+            # one-channel image that needs no gradient is boundary plumbing (a torch op), like the layout conversion.
+            assert torch.is_tensor(x), "an interpolating encoder block takes the input image"
+            h = F.interpolate(x.detach().float(), scale_factor=self.downsc, mode="bilinear", align_corners=False)
         for j in range(self.groups):
-            y = rt.conv(h, f"{prefix}{1 + 3 * j}.weight", stats="instance")
+            if torch.is_tensor(h):
+                y = rt.conv_first(h, f"{prefix}1.weight", None, stats="instance")
+            else:
+                y = rt.conv(h, f"{prefix}{1 + 3 * j}.weight", stats="instance")
             h = rt.in_up_relu(y, upsample=False, out=out if j == self.groups - 1 else None)
         return h
 
@@ -584,3 +589,62 @@ class UNetSimpleReduced(SegkNet):
         d2 = self.dec2.emit(rt, "dec2.", [d3, c2], out=Act(cat1, 0, cs // 2))
         e = rt.conv([d2, c1], "dec1.0.weight", "dec1.0.bias", relu=True)
         return rt.head(e, "final.weight", "final.bias")
+
+
+class SpiderNet(SegkNet):
+    """Five branches that see the input at 2x, 1x, 1/2, 1/4 and 1/8 resolution, each encoded and decoded back to full
+    resolution, concatenated in front of a 1x1 head (reference :896-993).  Every branch re-scales the input image itself;
+    no tensor is shared between branches before the head."""
+    _BRANCHES = ((4, 3), (3, 2), (2, 1), (1, None), (0, -1))       # (index k of conv{k}/dec{k}, log2 of the down-scaling)
+
+    def __init__(self, out_classes=3, patch_train=False, in_classes=1, channelscale=64, multiout=False, noupdownsam=False):
+        super().__init__()
+        cs = channelscale
+        self.multiout, self.patch_train, self.channelscale, self.noupdownsam = multiout, patch_train, cs, noupdownsam
+        enc = dict(no_dsam=noupdownsam, if_interpolate=True)
+        self.conv0 = make_encoder_block(in_classes, cs // 2, cs // 2, convs3=False, downsc=2, **enc)
+        self.conv1 = _stem_modules(in_classes, cs)
+        self.conv2 = make_encoder_block(in_classes, 2 * cs, 2 * cs, convs3=False, downsc=0.5, **enc)
+        self.conv3 = make_encoder_block(in_classes, 4 * cs, 4 * cs, middle_channels2=4 * cs, downsc=0.25, **enc)
+        self.conv4 = make_encoder_block(in_classes, 8 * cs, 8 * cs, middle_channels2=8 * cs, downsc=1 / 8, **enc)
+        # never used by forward (reference :977 is commented out); kept for the state_dict layout
+        self.conv5 = nn.Sequential(
+            nn.Conv2d(cs + 2 * cs + 4 * cs + 8 * cs, 8 * cs, kernel_size=3, padding=1), nn.InstanceNorm2d(512),
+            nn.Conv2d(12 * cs, 8 * cs, kernel_size=(3, 3), padding=(1, 1)), nn.ReLU(inplace=True),
+            nn.Conv2d(8 * cs, 8 * cs, kernel_size=3, padding=1), nn.InstanceNorm2d(8 * cs), nn.ReLU(inplace=True))
+        self.dec4 = make_decoder_block(8 * cs, 8 * cs, 4 * cs, noupsam=noupdownsam, upsc=8)
+        self.dec3 = make_decoder_block(4 * cs, 4 * cs, cs, noupsam=noupdownsam, upsc=4)
+        self.dec2 = make_decoder_block(2 * cs, 2 * cs, cs // 2, noupsam=noupdownsam, upsc=2)
+        self.dec1 = nn.Sequential(nn.Conv2d(cs, cs // 2, 3, padding=1), nn.ReLU(inplace=True))
+        self.dec0 = make_decoder_block(cs // 2, cs // 2, cs // 4, noupsam=noupdownsam, upsc=0.5)
+        self.final = nn.Conv2d(4 * cs + cs + cs // 2 + cs // 2 + cs // 4, out_classes, kernel_size=1)
+
+    def _forward_host(self, x):
+        decs = [getattr(self, f"dec{k}")(getattr(self, f"conv{k}")(x)) for k in (4, 3, 2, 1, 0)]
+        out = self.final(torch.cat(decs, 1))
+        return (out, decs[::-1]) if self.multiout else out
+
+    def _emit(self, rt, x):
+        N, _, H, W = x.shape
+        cs = self.channelscale
+        if self.noupdownsam:
+            raise NotImplementedError("SpiderNet(noupdownsam=True) mixes resolutions in its final concatenation and fails in the reference too")
+        if cs % 32:
+            raise NotImplementedError("channelscale must be a multiple of 32 (8-channel storage groups)")
+        if H % 8 or W % 8:
+            raise RuntimeError(f"SpiderNet needs H and W divisible by 8, got {H}x{W}")
+        widths = {4: 4 * cs, 3: cs, 2: cs // 2, 1: cs // 2, 0: cs // 4}
+        cat = rt.new(N, H, W, sum(widths.values())).buf             # [dec4 | dec3 | dec2 | dec1 | dec0] (reference :993)
+        decs, c0 = {}, 0
+        for k in (4, 3, 2, 1, 0):
+            out = Act(cat, c0, widths[k])
+            c0 += widths[k]
+            if k == 1:
+                h = _emit_stem(rt, x, None)
+                decs[k] = rt.conv(h, "dec1.0.weight", "dec1.0.bias", relu=True, out=out)
+            else:
+                h = getattr(self, f"conv{k}").emit(rt, f"conv{k}.", x)
+                decs[k] = getattr(self, f"dec{k}").emit(rt, f"dec{k}.", h, out=out)
+        rt.unused(["conv5.0.weight", "conv5.0.bias", "conv5.2.weight", "conv5.2.bias", "conv5.4.weight", "conv5.4.bias"])
+        logits = rt.head_wide([decs[k] for k in (4, 3, 2, 1, 0)], "final.weight", "final.bias")
+        return (logits, [rt.export(decs[k]) for k in (0, 1, 2, 3, 4)]) if self.multiout else logits

@@ -308,7 +308,7 @@ class Runtime:
             return [one(x[0]), one(x[1])]
         return [one(x)]
 
-    def _dgrad(self, segs, dy, wb, Cin):
+    def _dgrad(self, segs, dy, wb, Cin, taps=9):
         """Data gradient of a convolution into the gradient slices of its input segments."""
         def mask_of(members):
             """Act covering the leading members whose ReLU backward is left to this consumer (or None)."""
@@ -335,14 +335,14 @@ class Runtime:
 
         if len(segs) == 1:
             act, members = segs[0]
-            ops.conv_fwd(dy, wb, act.C, self.grad_of(act), taps=9, mask=mask_of(members), accumulate=state(members))
+            ops.conv_fwd(dy, wb, act.C, self.grad_of(act), taps=taps, mask=mask_of(members), accumulate=state(members))
             for m in members:
                 m.ready = True
             return
         # two segments: the kernel writes each segment's gradient straight into its own buffer
         (act0, mem0), (act1, mem1) = segs
         assert mask_of(mem0) is None and mask_of(mem1) is None
-        ops.conv_fwd(dy, wb, Cin, (self.grad_of(act0), self.grad_of(act1)), taps=9, accumulate=state(mem0), accumulate1=state(mem1))
+        ops.conv_fwd(dy, wb, Cin, (self.grad_of(act0), self.grad_of(act1)), taps=taps, accumulate=state(mem0), accumulate1=state(mem1))
         for m in mem0 + mem1:
             m.ready = True
 
@@ -451,8 +451,9 @@ class Runtime:
         self.record(bwd)
         return p
 
-    def in_up_relu(self, y, out=None, eps=1e-5, upsample=True, relu=True):
-        """InstanceNorm2d(affine=False) -> bilinear x2 (align_corners=False) -> ReLU, one pass over the output.
+    def in_up_relu(self, y, out=None, eps=1e-5, upsample=True, relu=True, scale=2):
+        """InstanceNorm2d(affine=False) -> bilinear resize by `scale` (align_corners=False) -> ReLU, one pass over the
+        output (scale 2: the specialised kernels; 8, 4, 0.5 ...: the general ones).
         upsample=False: InstanceNorm2d (-> ReLU unless relu=False) at the input's size."""
         assert relu or not upsample
         x = y.act
@@ -460,8 +461,11 @@ class Runtime:
         self._norm_stats(y, x.N, eps, stats)
         if upsample:
             # u = relu(...): the ReLU backward is applied by the consumer's data gradient (relu_fused)
-            u = Var(out or self.new(x.N, 2 * x.H, 2 * x.W, x.C), relu_fused=True)
-            ops.upsample_fwd(x, u.act, stats=stats, relu=True, align=False)
+            u = Var(out or self.new(x.N, int(x.H * scale), int(x.W * scale), x.C), relu_fused=True)
+            if scale == 2:
+                ops.upsample_fwd(x, u.act, stats=stats, relu=True, align=False)
+            else:
+                ops.resize_fwd(x, u.act, scale, stats=stats, relu=True)
         else:
             u = Var(out or self.new(x.N, x.H, x.W, x.C))
             ops.norm_apply(x, x.N, stats, None, None, relu, u.act)
@@ -471,7 +475,10 @@ class Runtime:
             dy = self.grad_of(x)
             if upsample:
                 dxh = self.new(x.N, x.H, x.W, x.C)
-                ops.upsample_bwd(du, None, dxh, relu=False, align=False)
+                if scale == 2:
+                    ops.upsample_bwd(du, None, dxh, relu=False, align=False)
+                else:
+                    ops.resize_bwd(du, dxh, scale)
                 ops.norm_bwd(dxh, x, x.N, stats, None, None, False, dy)
             else:
                 ops.norm_bwd(du, x, x.N, stats, None, None, relu, dy)
@@ -509,7 +516,42 @@ class Runtime:
         self._head = (e, w, wname, bname, logits)
         return logits
 
+    def head_wide(self, x, wname, bname):
+        """1x1 classification head over a wide concatenated input (models/unetvgg.py:962-967,993: 6.25 x channelscale
+        channels): a 1x1 convolution on the matrix cores with the class count padded to 8 output channels -> NCHW fp32
+        logits.  x: list of Vars tiling one buffer."""
+        w = self.p[wname].detach()
+        Cout = w.shape[0]
+        segs = self._segments(x)
+        act = segs[0][0]
+        assert len(segs) == 1 and Cout <= 8
+        w1 = torch.zeros(8, act.C, 1, 1, dtype=torch.float32, device=self.device)
+        w1[:Cout] = w.reshape(Cout, act.C, 1, 1)
+        wf, wb = ops.conv_pack(w1, self.dtype, want_fwd=True, want_bwd=self.need_grad)
+        y = self.new(act.N, act.H, act.W, 8)
+        ops.conv_fwd(act, wf, 8, y, taps=1, bias=self._bias(bname, 8))
+        logits = y.nchw()[:, :Cout].float().contiguous()
+        self._head = (None, w, wname, bname, logits, segs, wb)
+        return logits
+
+    def _head_wide_backward(self, dlogits):
+        _, w, wname, bname, _, segs, wb = self._head
+        Cout, act = w.shape[0], segs[0][0]
+        dy = ops.nchw_to_nhwc(dlogits.contiguous().float(), self.dtype, C=8)       # channels past Cout are zero
+        dw8 = torch.empty(8, act.C, dtype=torch.float32, device=self.device)
+        ops.conv_wgrad(act, dy, dw8, taps=1)
+        dw = self.alloc_grad(wname, w)
+        dw.copy_(dw8[:Cout].view_as(w))
+        self._emit(wname, dw)
+        db8 = ops.colsum(dy, torch.empty(8, dtype=torch.float32, device=self.device))
+        db = self.alloc_grad(bname, self.p[bname])
+        db.copy_(db8[:Cout])
+        self._emit(bname, db)
+        self._dgrad(segs, dy, wb, act.C, taps=1)
+
     def head_backward(self, dlogits):
+        if self._head[0] is None:
+            return self._head_wide_backward(dlogits)
         e, w, wname, bname, _ = self._head
         Cout = w.shape[0]
         dl = dlogits.contiguous().float()
@@ -519,3 +561,14 @@ class Runtime:
         e.ready = True
         self._emit(wname, dw)
         self._emit(bname, db)
+
+    def unused(self, names):
+        """Parameters outside the graph of this call: their gradient is zero where a flat gradient buffer expects one."""
+        def bwd():
+            if self.grad_alloc is None:
+                return
+            for n in names:
+                g = self.alloc_grad(n, self.p[n])
+                self._zero_grad(n, g)
+                self._emit(n, g)
+        self.record(bwd)

@@ -195,14 +195,3 @@ class Runtime3D(Runtime):
             self._emit(bn_, gb)
             d = d @ w
         feats_bwd(d)
-
-    def unused(self, names):
-        """Parameters outside the graph of this call: their gradient is zero where a flat gradient buffer expects one."""
-        def bwd():
-            if self.grad_alloc is None:
-                return
-            for n in names:
-                g = self.alloc_grad(n, self.p[n])
-                self._zero_grad(n, g)
-                self._emit(n, g)
-        self.record(bwd)

@@ -25,7 +25,7 @@ class GradBuckets:
         for name, n in sizes:
             self.offsets[name] = (off, n)
             self.bucket_of[name] = b
-            off += n
+            off += (n + 63) // 64 * 64         # every tensor starts on a 256-byte boundary (the kernels need 16; padding stays zero)
             if (off - start) * 4 >= bucket_bytes:
                 self.ranges.append((start, off))
                 start, b = off, b + 1
@@ -99,10 +99,10 @@ class FlatModel:
         named = list(net.named_parameters())[::-1]            # backward completion order
         device = named[0][1].device
         sizes = [(n, p.numel()) for n, p in named]
-        total = sum(s for _, s in sizes)
-        self.flat_param = torch.empty(total, dtype=torch.float32, device=device)
-        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.buckets = GradBuckets(sizes, int(bucket_mb * (1 << 20)), group=group, device=device)
+        total = self.buckets.total
+        self.flat_param = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.views = {}
         for n, p in named:
             off, cnt = self.buckets.offsets[n]

@@ -211,7 +211,7 @@ def _model_fixture(name, mk_ref, mk_or, in_ch, n_cls, out, keys, pin, dice_ref, 
         same = same and bits_equal(fa, fb)
         out[f"{name}/feat{i}_sub"] = fa[..., ::4, ::4].contiguous().numpy()
     for (ka, pa), (_, pb) in zip(m_ref.named_parameters(), m_or.named_parameters()):
-        same = same and bits_equal(pa.grad, pb.grad)
+        same = same and ((pa.grad is None and pb.grad is None) or bits_equal(pa.grad, pb.grad))    # None: never used by forward
     for (ka, ba), (_, bb) in zip(m_ref.named_buffers(), m_or.named_buffers()):
         same = same and bits_equal(ba, bb)
     pin[f"model/{name}"] = bool(same)
@@ -221,6 +221,8 @@ def _model_fixture(name, mk_ref, mk_or, in_ch, n_cls, out, keys, pin, dice_ref, 
     top2 = la.topk(2, dim=1).values
     out[f"{name}/near_tie_1e-3"] = np.int64(((top2[:, 0] - top2[:, 1]) < 1e-3).sum().item())
     for k, p in m_ref.named_parameters():
+        if p.grad is None:
+            continue
         g = p.grad.flatten()
         out[f"{name}/grad_norm/{k}"] = np.float64(g.double().norm().item())
         out[f"{name}/grad_head/{k}"] = g[:16].numpy().copy()
@@ -282,6 +284,9 @@ def variant_cases(ref):
         ("unetnaivemulti_c4", lambda: uv.UNetNaiveMultiOut(out_classes=4, in_classes=1), lambda: RM.RefUNetFourLevel(out_classes=4), 1),
         ("unetlimmulti_c4", lambda: uv.UNetLimMultiOut(out_classes=4, in_classes=1, multiout=True),
          lambda: RM.RefUNetFourLevel(out_classes=4, channel_depth=16), 1),
+        ("spidernet_c4", lambda: uv.SpiderNet(out_classes=4, in_classes=1), lambda: RM.RefSpiderNet(out_classes=4), 1),
+        ("spidernet_multi_cs32_c3", lambda: uv.SpiderNet(out_classes=3, in_classes=1, channelscale=32, multiout=True),
+         lambda: RM.RefSpiderNet(out_classes=3, channelscale=32, multiout=True), 1),
         ("unetskip_multi_c4", lambda: uv.UNetSkip(out_classes=4, in_classes=1, multiout=True),
          lambda: RM.RefUNetSimple(out_classes=4, in_classes=1, channelscale=32, multiout="dec4"), 1),
         ("unetsimplereduced_cs32_c3", lambda: uv.UNetSimpleReduced(out_classes=3, in_classes=1, channelscale=32),

@@ -7,7 +7,7 @@ Plain `torch.nn` restatement of the two graded networks with the reference's sta
 * plain InstanceNorm U-Nets             -- /root/reference/models/unetvgg.py:268-323 (encoder block), :335-372 (center),
                                            :373-440 (UNetNaive), :443-506 (UNetWithoutCenter), :509-574 (UNetNaiveMultiOut),
                                            :576-648 (UNetLimMultiOut), :651-728 (UNetSimple), :730-813 (UNetSkip),
-                                           :815-894 (UNetSimpleReduced)
+                                           :815-894 (UNetSimpleReduced), :896-993 (SpiderNet)
 * nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
 * 3-D DenseNet-BC classifier + DetectMid -- /root/reference/models/densenet3d.py:10-159, 162-186;
                                            /root/reference/models/resnt.py:8-45
@@ -239,6 +239,42 @@ class RefUNetSimpleReduced(nn.Module):
         d = self.dec3(torch.cat([self.dec4(c3), c3], 1))
         d = self.dec2(torch.cat([d, c2], 1))
         return self.final(self.dec1(torch.cat([d, c1], 1)))
+
+
+def _interp_encoder(in_classes, c_mid, c_out, scale, convs3=True, c_mid2=None):
+    """unetvgg.py:268-323 with if_interpolate=True: the block opens with a bilinear re-scaling of its input."""
+    mods, c = [nn.Upsample(scale_factor=scale, mode="bilinear", align_corners=False)], in_classes
+    for wdt in [c_mid] + ([c_mid2] if convs3 else []) + [c_out]:
+        mods += [nn.Conv2d(c, wdt, 3, padding=1, bias=False), nn.InstanceNorm2d(wdt), nn.ReLU(inplace=True)]
+        c = wdt
+    return nn.Sequential(*mods)
+
+
+class RefSpiderNet(nn.Module):
+    """unetvgg.py:896-993; conv5 exists in the state_dict and is never called."""
+
+    def __init__(self, out_classes=3, in_classes=1, channelscale=64, multiout=False):
+        super().__init__()
+        cs, self.multiout = channelscale, multiout
+        self.conv0 = _interp_encoder(in_classes, cs // 2, cs // 2, 2, convs3=False)
+        self.conv1 = _in_stem(in_classes, cs)
+        self.conv2 = _interp_encoder(in_classes, 2 * cs, 2 * cs, 0.5, convs3=False)
+        self.conv3 = _interp_encoder(in_classes, 4 * cs, 4 * cs, 0.25, c_mid2=4 * cs)
+        self.conv4 = _interp_encoder(in_classes, 8 * cs, 8 * cs, 1 / 8, c_mid2=8 * cs)
+        self.conv5 = nn.Sequential(nn.Conv2d(15 * cs, 8 * cs, 3, padding=1), nn.InstanceNorm2d(8 * cs),
+                                   nn.Conv2d(12 * cs, 8 * cs, 3, padding=1), nn.ReLU(inplace=True),
+                                   nn.Conv2d(8 * cs, 8 * cs, 3, padding=1), nn.InstanceNorm2d(8 * cs), nn.ReLU(inplace=True))
+        self.dec4 = decoder_block(8 * cs, 8 * cs, 4 * cs, upsc=8)
+        self.dec3 = decoder_block(4 * cs, 4 * cs, cs, upsc=4)
+        self.dec2 = decoder_block(2 * cs, 2 * cs, cs // 2, upsc=2)
+        self.dec1 = nn.Sequential(nn.Conv2d(cs, cs // 2, 3, padding=1), nn.ReLU(inplace=True))
+        self.dec0 = decoder_block(cs // 2, cs // 2, cs // 4, upsc=0.5)
+        self.final = nn.Conv2d(4 * cs + cs + cs // 2 + cs // 2 + cs // 4, out_classes, 1)
+
+    def forward(self, x):
+        d = [getattr(self, f"dec{k}")(getattr(self, f"conv{k}")(x)) for k in range(5)]
+        y = self.final(torch.cat(d[::-1], 1))
+        return (y, d) if self.multiout else y
 
 
 class RefDoubleConv(nn.Module):

@@ -38,4 +38,7 @@ def golden():
                 if key in f.files:
                     return f[key]
             raise KeyError(key)
+
+        def keys(self):
+            return {k for f in self.files for k in f.files}
     return {"losses": np.load(os.path.join(d, "losses.npz")), "models": Merged("models.npz", "variants.npz")}

@@ -79,8 +79,10 @@ def test_bucket_partition_covers_flat_buffer():
     sys.path.insert(0, os.path.join(root, "image-segmentation_amd"))
     from segk.flat import GradBuckets
     sizes = [("a", 1000), ("b", 10), ("c", 5000), ("d", 7), ("e", 3)]
-    b = GradBuckets(sizes, bucket_bytes=4 * 1005)
-    assert b.ranges[0][0] == 0 and b.ranges[-1][1] == 6020
+    b = GradBuckets(sizes, bucket_bytes=4 * 1030)
+    # every tensor starts on a 64-element (256-byte) boundary: 1024 + 64 + 5056 + 64 + 64
+    assert b.ranges[0][0] == 0 and b.ranges[-1][1] == 6272 == b.total
+    assert all(off % 64 == 0 for off, _ in b.offsets.values()) and b.offsets["c"] == (1088, 5000)
     for (lo, hi), (lo2, _) in zip(b.ranges, b.ranges[1:]):
         assert hi == lo2
     assert b.bucket_of["a"] == b.bucket_of["b"] == 0 and b.bucket_of["c"] == 1 and b.bucket_of["e"] == 2

@@ -89,6 +89,9 @@ def check_fp32_grads(name, model, side=64, n=2, tag=None):
     rows = []
     for (k, p), (_, q32), (_, q64) in zip(model.named_parameters(), m32.named_parameters(), m64.named_parameters()):
         g64 = q64.grad
+        if g64 is None:       # a parameter the forward never uses (SpiderNet.conv5)
+            assert p.grad is None or float(p.grad.abs().max()) == 0, k
+            continue
         scale = float(g64.norm())
         if scale < 1e-6:      # analytically zero gradients (conv bias in front of a batch-statistics norm)
             assert float(p.grad.norm()) < 1e-5, k
@@ -118,6 +121,9 @@ def test_fp32_step_vs_golden(name, golden):
     assert int((~safe).sum()) <= 4 * int(g[f"{name}/near_tie_1e-3"]) + 8
     # gradients: golden norms within the reference's own noise band, full tensors against the fp64 oracle
     for k, p in model.named_parameters():
+        if f"{name}/grad_norm/{k}" not in g.keys():      # never used by the reference's forward: no gradient there either
+            assert p.grad is None or float(p.grad.abs().max()) == 0, k
+            continue
         assert p.grad is not None, k
         gn = float(g[f"{name}/grad_norm/{k}"])
         if gn > 1e-6:   # loose band: the reference's own fp32 noise on these norms reaches ~1e-2 on tiny tensors
@@ -316,3 +322,33 @@ def test_unetsimple_reference_width_vs_oracle():
     with torch.no_grad():
         e = rel_l2(model(x.cuda()).cpu(), want.detach())
     assert e < 5e-2, e
+
+
+def test_spidernet_flat_adam_and_bf16():
+    """SpiderNet as perlosstrain/train_percloss.py:39 builds it (multiout): a step through the flat parameter / gradient
+    buffers with the fused Adam (its never-used conv5 parameters get a zero gradient there), and bf16 logits against the
+    fp32 oracle."""
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetvgg import SpiderNet
+    from oracle.ref_models import RefSpiderNet, hash_init_, synthetic_batch
+    from segk.flat import FlatModel
+    from segk.optim import Adam
+    x, t = synthetic_batch(2, 64, 3, in_ch=1, tag="model:spidernet_flat")
+    ref = hash_init_(RefSpiderNet(out_classes=3, channelscale=32, multiout=True)).train()
+    want, _ = ref(x)
+    model = hash_init_(SpiderNet(out_classes=3, channelscale=32, multiout=True)).cuda().train().set_compute_dtype(torch.bfloat16)
+    flat = FlatModel(model)
+    opt = Adam(flat, lr=1e-3)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    logits, feats, loss = step_loss(model(x.cuda()), t.cuda(), dice_loss_sq, focal_loss_with_logits)
+    assert rel_l2(logits, want) < 5e-2 and len(feats) == 5
+    loss.backward()
+    opt.step()
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        moved = float((p.detach() - before[k]).abs().max())
+        if k.startswith("conv5."):
+            assert moved == 0.0 and float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert torch.isfinite(p).all() and (moved > 0.0 or float(p.grad.abs().max()) < 1e-12), k

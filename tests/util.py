@@ -43,6 +43,9 @@ VARIANTS = {
                                  "RefUNetSimple", dict(out_classes=3, channelscale=32, multiout=True)),
     "unetnaivemulti_c4": ("UNetNaiveMultiOut", dict(out_classes=4, in_classes=1), "RefUNetFourLevel", dict(out_classes=4)),
     "unetlimmulti_c4": ("UNetLimMultiOut", dict(out_classes=4, in_classes=1, multiout=True), "RefUNetFourLevel", dict(out_classes=4, channel_depth=16)),
+    "spidernet_c4": ("SpiderNet", dict(out_classes=4, in_classes=1), "RefSpiderNet", dict(out_classes=4)),
+    "spidernet_multi_cs32_c3": ("SpiderNet", dict(out_classes=3, in_classes=1, channelscale=32, multiout=True),
+                                "RefSpiderNet", dict(out_classes=3, channelscale=32, multiout=True)),
     "unetskip_multi_c4": ("UNetSkip", dict(out_classes=4, in_classes=1, multiout=True), "RefUNetSimple", dict(out_classes=4, channelscale=32, multiout="dec4")),
     "unetsimplereduced_cs32_c3": ("UNetSimpleReduced", dict(out_classes=3, in_classes=1, channelscale=32), "RefUNetSimpleReduced", dict(out_classes=3, channelscale=32)),
 }
