@@ -4,7 +4,7 @@ Same constructor signatures, attribute names and state_dict layout as the refere
 (/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213,
 make_encoder_block :268-323, make_center :335-372, UNetNaive :373-440, UNetWithoutCenter :443-506,
 UNetNaiveMultiOut :509-574, UNetLimMultiOut :576-648, UNetSimple :651-728, UNetSkip :730-813,
-UNetSimpleReduced :815-894, SpiderNet :896-993),
+UNetSimpleReduced :815-894, SpiderNet :896-993, UNetTetra :996-1095),
 so checkpoints and callers are interchangeable.  The module tree is made of ordinary torch.nn layers
 that only hold the parameters (and serve CPU tensors); for CUDA tensors `forward` hands the
 parameters to the segk tape (segk/engine.py), which launches the HIP kernels: implicit-GEMM
@@ -226,13 +226,13 @@ def _emit_stem(rt, x, out):
     return rt.in_up_relu(y, upsample=False, out=out)
 
 
-def _emit_bottom(rt, c4, out):
+def _emit_bottom(rt, c4, out, prefix="conv5"):
     """conv5 of reference :471-480 / :690-699: conv, InstanceNorm (no ReLU), conv, ReLU, conv, InstanceNorm, ReLU.
     A bias in front of an InstanceNorm cancels: its gradient is exactly zero."""
-    y = rt.conv(c4, "conv5.0.weight", "conv5.0.bias", stats="instance", bias_grad_zero=True)
+    y = rt.conv(c4, f"{prefix}.0.weight", f"{prefix}.0.bias", stats="instance", bias_grad_zero=True)
     h = rt.in_up_relu(y, upsample=False, relu=False)
-    h = rt.conv(h, "conv5.2.weight", "conv5.2.bias", relu=True)
-    y = rt.conv(h, "conv5.4.weight", "conv5.4.bias", stats="instance", bias_grad_zero=True)
+    h = rt.conv(h, f"{prefix}.2.weight", f"{prefix}.2.bias", relu=True)
+    y = rt.conv(h, f"{prefix}.4.weight", f"{prefix}.4.bias", stats="instance", bias_grad_zero=True)
     return rt.in_up_relu(y, upsample=False, out=out)
 
 
@@ -648,3 +648,78 @@ class SpiderNet(SegkNet):
         rt.unused(["conv5.0.weight", "conv5.0.bias", "conv5.2.weight", "conv5.2.bias", "conv5.4.weight", "conv5.4.bias"])
         logits = rt.head_wide([decs[k] for k in (4, 3, 2, 1, 0)], "final.weight", "final.bias")
         return (logits, [rt.export(decs[k]) for k in (0, 1, 2, 3, 4)]) if self.multiout else logits
+
+
+def _bottom_modules(cs):
+    # the two InstanceNorm2d widths are the reference's literals; without affine parameters the width is unused
+    return nn.Sequential(
+        nn.Conv2d(8 * cs, 8 * cs, kernel_size=3, padding=1), nn.InstanceNorm2d(512),
+        nn.Conv2d(8 * cs, 8 * cs, kernel_size=(3, 3), padding=(1, 1)), nn.ReLU(inplace=True),
+        nn.Conv2d(8 * cs, 8 * cs, kernel_size=3, padding=1), nn.InstanceNorm2d(4 * cs), nn.ReLU(inplace=True))
+
+
+class UNetTetra(SegkNet):
+    """UNetSimple with a second bottom stage (conv15) and a second head (final1) for edges (reference :996-1095).  Its forward
+    decodes the second branch with the FIRST branch's dec4..dec1 (:1090-1093), so those weights receive the sum of both
+    branches' gradients and dec14..dec11 are never used; both facts are reproduced.  Returns (final(dec1), final1(dec11))."""
+
+    def __init__(self, pretrained=False, out_classes=3, patch_train=False, in_classes=1, channelscale=64, multiout=False,
+                 noupdownsam=False):
+        super().__init__()
+        cs = channelscale
+        self.multiout, self.patch_train, self.channelscale, self.noupdownsam = multiout, patch_train, cs, noupdownsam
+        self.conv1 = _stem_modules(in_classes, cs)
+        self.conv2 = make_encoder_block(cs, 2 * cs, 2 * cs, convs3=False, no_dsam=noupdownsam)
+        self.conv3 = make_encoder_block(2 * cs, 4 * cs, 4 * cs, middle_channels2=4 * cs, no_dsam=noupdownsam)
+        self.conv4 = make_encoder_block(4 * cs, 8 * cs, 8 * cs, middle_channels2=8 * cs, no_dsam=noupdownsam)
+        self.conv5 = _bottom_modules(cs)
+        for tag, head in (("", "final"), ("1", "final1")):
+            if tag:
+                self.conv15 = _bottom_modules(cs)
+            setattr(self, f"dec{tag}4", make_decoder_block(16 * cs, 8 * cs, 4 * cs, noupsam=noupdownsam))
+            setattr(self, f"dec{tag}3", make_decoder_block(8 * cs, 4 * cs, cs, noupsam=noupdownsam))
+            setattr(self, f"dec{tag}2", make_decoder_block(3 * cs, 2 * cs, cs // 2, noupsam=noupdownsam))
+            setattr(self, f"dec{tag}1", nn.Sequential(nn.Conv2d(int(1.5 * cs), cs // 2, 3, padding=1), nn.ReLU(inplace=True)))
+            setattr(self, head, nn.Conv2d(cs // 2, out_classes, kernel_size=1))
+
+    def _forward_host(self, x):
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c4 = self.conv4(c3)
+        outs = []
+        for bottom, head in ((self.conv5, self.final), (self.conv15, self.final1)):
+            d = self.dec4(torch.cat([bottom(c4), c4], 1))
+            d = self.dec3(torch.cat([d, c3], 1))
+            d = self.dec2(torch.cat([d, c2], 1))
+            outs.append(head(self.dec1(torch.cat([d, c1], 1))))
+        return outs[0], outs[1]
+
+    def _pack_outputs(self, logits, feats):
+        return logits, feats[0]
+
+    def _emit(self, rt, x):
+        N, _, H, W = x.shape
+        cs, down = self.channelscale, not self.noupdownsam
+        if cs % 16:
+            raise NotImplementedError("channelscale must be a multiple of 16 (8-channel storage groups)")
+        if down and (H % 8 or W % 8):
+            raise RuntimeError(f"UNetTetra needs H and W divisible by 8 (three stride-2 convolutions), got {H}x{W}")
+        dec_w, enc_w = {1: cs // 2, 2: cs, 3: 4 * cs, 4: 8 * cs}, {1: cs, 2: 2 * cs, 3: 4 * cs, 4: 8 * cs}
+
+        def buffers():
+            return {k: rt.new(N, H >> (k - 1) if down else H, W >> (k - 1) if down else W, dec_w[k] + enc_w[k]).buf for k in range(1, 5)}
+        cat, cat2 = buffers(), buffers()          # [decoder tensor | encoder skip] per level, one set per branch
+        skips = {1: _emit_stem(rt, x, Act(cat[1], dec_w[1], enc_w[1]))}
+        for k in range(2, 5):
+            skips[k] = getattr(self, f"conv{k}").emit(rt, f"conv{k}.", skips[k - 1], out=Act(cat[k], dec_w[k], enc_w[k]))
+        outs = []
+        for bufs, bottom, head in ((cat, "conv5", "final"), (cat2, "conv15", "final1")):
+            sk = skips if bufs is cat else {k: rt.copy(skips[k], Act(bufs[k], dec_w[k], enc_w[k])) for k in range(1, 5)}
+            d = _emit_bottom(rt, skips[4], Act(bufs[4], 0, dec_w[4]), prefix=bottom)
+            for k in (4, 3, 2):
+                d = getattr(self, f"dec{k}").emit(rt, f"dec{k}.", [d, sk[k]], out=Act(bufs[k - 1], 0, dec_w[k - 1]))
+            e = rt.conv([d, sk[1]], "dec1.0.weight", "dec1.0.bias", relu=True)
+            outs.append(rt.head(e, f"{head}.weight", f"{head}.bias"))
+        rt.unused([n for n, _ in self.named_parameters() if n.startswith(("dec14.", "dec13.", "dec12.", "dec11."))])
+        return outs[0], [outs[1]]

@@ -60,6 +60,8 @@ class Runtime:
         self.counters = []                      # BatchNorm num_batches_tracked buffers to bump once, together
         self.pack_plan = None                   # segk.packplan.PackPlan of the network (None: pack layer by layer)
         self.exports = []                       # intermediate tensors handed to the caller next to the logits
+        self._packed = set()
+        self._uses, self._shared, self._left = {}, {}, {}   # parameters used by several layers (models/unetvgg.py:1090-1093)
 
     # ---------------------------------------------------------------- buffers
     def new(self, N, H, W, C, zero=False):
@@ -164,6 +166,9 @@ class Runtime:
         """Add the callers' gradients of the exported tensors (None: unused) to the tape's gradient buffers.  Runs after
         the head's backward and before the recorded closures."""
         for var, g in zip(self.exports, grads):
+            if isinstance(var, tuple):           # a second head: its backward seeds the gradient of its own branch
+                self.head_backward(g if g is not None else torch.zeros_like(var[4]), record=var)
+                continue
             if g is None:
                 continue
             tmp = ops.nchw_to_nhwc(g, self.dtype, C=var.act.C)
@@ -182,8 +187,9 @@ class Runtime:
         With a replayed PackPlan the images were already written by this forward's single batched launch."""
         key = (wname, seg0)
         plan = self.pack_plan
-        if plan is not None and plan.ready and key in plan.entries:
-            return plan.entries[key]
+        if plan is not None and key in plan.entries and (plan.ready or key in self._packed):
+            return plan.entries[key]              # replayed plan, or a second layer using the same weight in this forward
+        self._packed.add(key)
         w = self.p[wname].detach()
         if view is not None:
             w = w.reshape(view)
@@ -273,24 +279,57 @@ class Runtime:
         ops.conv_fwd(xin, wf, Cout, y.act, taps=9, bias=self._bias(bname), relu=relu,
                      stat_partials=self._stat_buffer(y, stats, norm_groups=y.act.N if stats == "instance" else None))
 
+        for name in (wname, bname):
+            if name is not None:
+                self._uses[name] = self._uses.get(name, 0) + 1
+
         def bwd():
             dy = self.grad_of(y.act)
-            dw = self.alloc_grad(wname, w)
-            db = self.alloc_grad(bname, self.p[bname]) if bname is not None else None
+            dw, more_w = self._param_grad(wname, w)
+            db, more_b = self._param_grad(bname, self.p[bname]) if bname is not None else (None, False)
             with self.side():
-                ops.conv_wgrad(xin, dy, dw, taps=9, cin_real=Cin)
-                self._emit(wname, dw)
+                ops.conv_wgrad(xin, dy, dw, taps=9, cin_real=Cin, accumulate=more_w)
+                self._param_done(wname, dw)
                 if bname is not None:
                     if bias_grad_zero:
+                        assert not more_b
                         self._zero_grad(bname, db)
                     else:
                         if self.zero_state is not None:
                             self.zero_state.discard(bname)
-                        ops.colsum(dy, db)
-                    self._emit(bname, db)
+                        ops.colsum(dy, db, accumulate=more_b)
+                    self._param_done(bname, db)
             self._dgrad(segs, dy, wb, Cin)
         self.record(bwd)
         return y
+
+    def _param_grad(self, name, like):
+        """-> (gradient tensor of parameter `name`, whether an earlier layer of this backward already wrote into it)."""
+        if name in self._shared:
+            return self._shared[name], True
+        g = self.alloc_grad(name, like)
+        if self._uses.get(name, 1) > 1:
+            self._shared[name] = g
+        return g, False
+
+    def _param_done(self, name, g):
+        """Publish the gradient once the last layer that uses the parameter has added its share."""
+        left = self._left.get(name, self._uses.get(name, 1)) - 1
+        self._left[name] = left
+        if left == 0:
+            self._emit(name, g)
+
+    def copy(self, a, out):
+        """Second copy of a tensor in another concat buffer (a skip tensor read by two decoder branches)."""
+        assert not a.relu_fused
+        v = Var(out)
+        ops.copy_slice(a.act, out)
+
+        def bwd():
+            ops.copy_slice(self.grad_of(out), self.grad_of(a.act), accumulate=a.ready)
+            a.ready = True
+        self.record(bwd)
+        return v
 
     def _segments(self, x):
         """-> list of (covering Act, [member Vars])."""
@@ -513,7 +552,11 @@ class Runtime:
         x = e.act
         logits = torch.empty(x.N, Cout, x.H, x.W, dtype=torch.float32, device=self.device)
         ops.head_fwd(x, w.reshape(Cout, -1).contiguous(), b, logits)
-        self._head = (e, w, wname, bname, logits)
+        record = (e, w, wname, bname, logits)
+        if getattr(self, "_head", None) is None:
+            self._head = record
+        else:                                   # a second head (models/unetvgg.py:1095): its logits leave as an extra output
+            self.exports.append(record)
         return logits
 
     def head_wide(self, x, wname, bname):
@@ -549,10 +592,10 @@ class Runtime:
         self._emit(bname, db)
         self._dgrad(segs, dy, wb, act.C, taps=1)
 
-    def head_backward(self, dlogits):
-        if self._head[0] is None:
+    def head_backward(self, dlogits, record=None):
+        if record is None and self._head[0] is None:
             return self._head_wide_backward(dlogits)
-        e, w, wname, bname, _ = self._head
+        e, w, wname, bname, _ = record or self._head
         Cout = w.shape[0]
         dl = dlogits.contiguous().float()
         dw = self.alloc_grad(wname, w)

@@ -287,6 +287,8 @@ def variant_cases(ref):
         ("spidernet_c4", lambda: uv.SpiderNet(out_classes=4, in_classes=1), lambda: RM.RefSpiderNet(out_classes=4), 1),
         ("spidernet_multi_cs32_c3", lambda: uv.SpiderNet(out_classes=3, in_classes=1, channelscale=32, multiout=True),
          lambda: RM.RefSpiderNet(out_classes=3, channelscale=32, multiout=True), 1),
+        ("unettetra_cs32_c4", lambda: uv.UNetTetra(out_classes=4, in_classes=1, channelscale=32),
+         lambda: RM.RefUNetTetra(out_classes=4, channelscale=32), 1),
         ("unetskip_multi_c4", lambda: uv.UNetSkip(out_classes=4, in_classes=1, multiout=True),
          lambda: RM.RefUNetSimple(out_classes=4, in_classes=1, channelscale=32, multiout="dec4"), 1),
         ("unetsimplereduced_cs32_c3", lambda: uv.UNetSimpleReduced(out_classes=3, in_classes=1, channelscale=32),

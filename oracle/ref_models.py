@@ -7,7 +7,7 @@ Plain `torch.nn` restatement of the two graded networks with the reference's sta
 * plain InstanceNorm U-Nets             -- /root/reference/models/unetvgg.py:268-323 (encoder block), :335-372 (center),
                                            :373-440 (UNetNaive), :443-506 (UNetWithoutCenter), :509-574 (UNetNaiveMultiOut),
                                            :576-648 (UNetLimMultiOut), :651-728 (UNetSimple), :730-813 (UNetSkip),
-                                           :815-894 (UNetSimpleReduced), :896-993 (SpiderNet)
+                                           :815-894 (UNetSimpleReduced), :896-993 (SpiderNet), :996-1095 (UNetTetra)
 * nested U-Net (UNet++)                 -- /root/reference/models/unetplusplus.py:6-25, 27-82
 * 3-D DenseNet-BC classifier + DetectMid -- /root/reference/models/densenet3d.py:10-159, 162-186;
                                            /root/reference/models/resnt.py:8-45
@@ -275,6 +275,36 @@ class RefSpiderNet(nn.Module):
         d = [getattr(self, f"dec{k}")(getattr(self, f"conv{k}")(x)) for k in range(5)]
         y = self.final(torch.cat(d[::-1], 1))
         return (y, d) if self.multiout else y
+
+
+class RefUNetTetra(RefUNetSimple):
+    """unetvgg.py:996-1095: a second bottom stage and head; the second branch is decoded with the FIRST branch's decoder
+    blocks (:1090-1093), the second set (dec14..dec11) exists in the state_dict and is never called."""
+
+    def __init__(self, out_classes=3, in_classes=1, channelscale=64):
+        super().__init__(out_classes=out_classes, in_classes=in_classes, channelscale=channelscale)
+        cs = channelscale
+        self.conv15 = nn.Sequential(nn.Conv2d(8 * cs, 8 * cs, 3, padding=1), nn.InstanceNorm2d(8 * cs),
+                                    nn.Conv2d(8 * cs, 8 * cs, 3, padding=1), nn.ReLU(inplace=True),
+                                    nn.Conv2d(8 * cs, 8 * cs, 3, padding=1), nn.InstanceNorm2d(8 * cs), nn.ReLU(inplace=True))
+        self.dec14 = decoder_block(16 * cs, 8 * cs, 4 * cs)
+        self.dec13 = decoder_block(8 * cs, 4 * cs, cs)
+        self.dec12 = decoder_block(3 * cs, 2 * cs, cs // 2)
+        self.dec11 = nn.Sequential(nn.Conv2d(cs + cs // 2, cs // 2, 3, padding=1), nn.ReLU(inplace=True))
+        self.final1 = nn.Conv2d(cs // 2, out_classes, 1)
+
+    def forward(self, x):
+        c1 = self.conv1(x)
+        c2 = self.conv2(c1)
+        c3 = self.conv3(c2)
+        c4 = self.conv4(c3)
+        outs = []
+        for bottom, head in ((self.conv5, self.final), (self.conv15, self.final1)):
+            d = self.dec4(torch.cat([bottom(c4), c4], 1))
+            d = self.dec3(torch.cat([d, c3], 1))
+            d = self.dec2(torch.cat([d, c2], 1))
+            outs.append(head(self.dec1(torch.cat([d, c1], 1))))
+        return outs[0], outs[1]
 
 
 class RefDoubleConv(nn.Module):

@@ -170,7 +170,7 @@ def test_state_dict_layout_matches_reference(name):
 
 
 @pytest.mark.parametrize("name", ["unetvgg_c4", "nestedunet_c4", "unetsimple_cs32_c3", "unetnaive_convtrans_pool_c3", "unetlimmulti_c4",
-                                  "unetsimple_multi_cs32_c3", "spidernet_multi_cs32_c3"])
+                                  "unetsimple_multi_cs32_c3", "spidernet_multi_cs32_c3", "unettetra_cs32_c4"])
 def test_oracle_and_host_path_match_golden(name, golden):
     """One train step on CPU: the oracle equals the golden vectors bit for bit, and the product's CPU-tensor
     path (plain torch.nn modules holding the same parameters) equals the oracle."""

@@ -46,6 +46,7 @@ VARIANTS = {
     "spidernet_c4": ("SpiderNet", dict(out_classes=4, in_classes=1), "RefSpiderNet", dict(out_classes=4)),
     "spidernet_multi_cs32_c3": ("SpiderNet", dict(out_classes=3, in_classes=1, channelscale=32, multiout=True),
                                 "RefSpiderNet", dict(out_classes=3, channelscale=32, multiout=True)),
+    "unettetra_cs32_c4": ("UNetTetra", dict(out_classes=4, in_classes=1, channelscale=32), "RefUNetTetra", dict(out_classes=4, channelscale=32)),
     "unetskip_multi_c4": ("UNetSkip", dict(out_classes=4, in_classes=1, multiout=True), "RefUNetSimple", dict(out_classes=4, channelscale=32, multiout="dec4")),
     "unetsimplereduced_cs32_c3": ("UNetSimpleReduced", dict(out_classes=3, in_classes=1, channelscale=32), "RefUNetSimpleReduced", dict(out_classes=3, channelscale=32)),
 }
