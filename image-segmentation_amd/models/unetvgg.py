@@ -1,7 +1,8 @@
 """U-Net with a VGG16-BN encoder, MI355X-native.
 
 Same constructor signatures, attribute names and state_dict layout as the reference classes
-(/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVggInOut :158-213,
+(/root/reference/models/unetvgg.py: make_decoder_block :6-41, UNetVgg :52-105, UNetVgg256 :107-132, UNetVggWholeImg :134-155,
+UNetVggInOut :158-213, UNetVggTwo :216-265,
 make_encoder_block :268-323, make_center :335-372, UNetNaive :373-440, UNetWithoutCenter :443-506,
 UNetNaiveMultiOut :509-574, UNetLimMultiOut :576-648, UNetSimple :651-728, UNetSkip :730-813,
 UNetSimpleReduced :815-894, SpiderNet :896-993, UNetTetra :996-1095),
@@ -723,3 +724,62 @@ class UNetTetra(SegkNet):
             outs.append(rt.head(e, f"{head}.weight", f"{head}.bias"))
         rt.unused([n for n, _ in self.named_parameters() if n.startswith(("dec14.", "dec13.", "dec12.", "dec11."))])
         return outs[0], [outs[1]]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Wrappers that re-size the image before and the logits after a VGG U-Net.  The re-sizing acts on NCHW images and logits
+# at the network boundary (nearest-neighbour interpolation, adaptive max pooling, cropping, padding: torch ops with
+# autograd); the network in between runs on the HIP tape.
+# ---------------------------------------------------------------------------------------------------------------------
+class UNetVgg256(nn.Module):
+    """Input resized to 128x128, three-class UNetVgg, logits max-pooled back to the input size (reference :107-132; the
+    `out_classes` argument is accepted and unused, as there)."""
+
+    def __init__(self, out_classes=3):
+        super().__init__()
+        self.unetvgg = UNetVgg()
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        out = self.unetvgg(F.interpolate(x, [128, 128]))
+        return F.adaptive_max_pool2d(out, size)
+
+
+class UNetVggWholeImg(nn.Module):
+    """Three-class UNetVgg initialised from a checkpoint's 'state_dict' entry (reference :134-155)."""
+
+    def __init__(self, save_model_path, out_classes=3):
+        super().__init__()
+        self.unetvgg = UNetVgg()
+        checkpoint = torch.load(save_model_path)
+        self.unetvgg.load_state_dict(checkpoint['state_dict'])
+
+    def forward(self, x):
+        return self.unetvgg(x)
+
+
+class UNetVggTwo(nn.Module):
+    """One UNetVggInOut per image half (reference :216-265): optional crop to the labelled region (+15 pixels), each half
+    resized to 256x256, logits max-pooled back to the half's size, halves joined, and the crop padded back with the
+    reference's own offsets (:264)."""
+
+    def __init__(self):
+        super().__init__()
+        self.unetvggl = UNetVggInOut()
+        self.unetvggr = UNetVggInOut()
+
+    def forward(self, x, y=None):
+        if y is not None:
+            rows, cols = torch.nonzero(y, as_tuple=True)[1], torch.nonzero(y, as_tuple=True)[2]
+            margin, full_h, full_w = 15, y.shape[-2], y.shape[-1]
+            top, bottom = max(0, rows.min() - margin), min(rows.max() + margin, full_h)
+            left, right = max(0, cols.min() - margin), min(cols.max() + margin, full_w)
+            x = x[:, :, top:bottom, left:right].clone()
+        height, width = x.shape[-2], x.shape[-1]
+        half = int(width / 2)
+        outl = self.unetvggl(F.interpolate(x[:, :, :, :half].clone(), [256, 256]))
+        outr = self.unetvggr(F.interpolate(x[:, :, :, half:].clone(), [256, 256]))
+        out = torch.cat((F.adaptive_max_pool2d(outl, [height, half]), F.adaptive_max_pool2d(outr, [height, width - half])), dim=-1)
+        if y is not None:
+            out = F.pad(out, (left - 1, full_w - right + 1, top - 1, full_h - bottom + 1))
+        return out

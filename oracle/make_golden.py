@@ -313,6 +313,40 @@ def golden_variants(ref, pin):
         json.dump(allkeys, f, indent=0)
 
 
+# ------------------------------------------------------------------------------------ re-sizing wrappers
+def golden_wrappers(ref, pin):
+    """UNetVgg256 (models/unetvgg.py:107-132) and UNetVggTwo (:216-265, with the label-driven crop): one training step each."""
+    uv, dice_ref, focal_ref = ref["models.unetvgg"], ref["loss.dice"], ref["loss.focal"]
+    out, keys = {}, {}
+    cases = [("unetvgg256", uv.UNetVgg256, RM.RefUNetVgg256, 3, False), ("unetvggtwo", uv.UNetVggTwo, RM.RefUNetVggTwo, 1, True)]
+    for name, mk_ref, mk_or, in_ch, with_labels in cases:
+        x, t = RM.synthetic_batch(2, 96, 3, in_ch=in_ch, tag=f"model:{name}")
+        res = []
+        for mk, dice, focal in ((mk_ref, dice_ref.dice_loss_sq, focal_ref.focal_loss_with_logits), (mk_or, RL.dice_loss_sq, RL.focal_loss_with_logits)):
+            m = RM.hash_init_(mk()).train()
+            y = m(x, t) if with_labels else m(x)
+            loss = dice(y, t) + focal(y, t)
+            loss.backward()
+            res.append((m, y.detach(), loss.detach()))
+        (ma, ya, la), (mb, yb, lb) = res
+        assert list(ma.state_dict().keys()) == list(mb.state_dict().keys()), name
+        same = bits_equal(ya, yb) and bits_equal(la, lb)
+        for (_, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            same = same and bits_equal(pa.grad, pb.grad)
+        pin[f"model/{name}"] = bool(same)
+        keys[name] = {k: list(v.shape) for k, v in ma.state_dict().items()}
+        out[f"{name}/logits"] = ya.numpy()
+        out[f"{name}/loss"] = la.numpy()
+        for k, p_ in ma.named_parameters():
+            out[f"{name}/grad_norm/{k}"] = np.float64(p_.grad.double().norm().item())
+    np.savez_compressed(os.path.join(GOLD, "wrappers.npz"), **out)
+    kf = os.path.join(GOLD, "state_dict_keys.json")
+    allkeys = json.load(open(kf)) if os.path.exists(kf) else {}
+    allkeys.update(keys)
+    with open(kf, "w") as f:
+        json.dump(allkeys, f, indent=0)
+
+
 # ------------------------------------------------------------------------------------ 3-D classifier
 # (2, 32, 128) volumes leave 2x2x2 voxels x 2 volumes = 16 samples per channel for the last block's BatchNorms; with
 # fewer (a 16x64x64 volume ends at ONE voxel, 2 samples) the network is chaotic: the reference's own fp32 and fp64 runs
@@ -371,7 +405,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
     pin = {}
-    partial = [a for a in ("--volumes-only", "--aux-losses-only", "--variants-only", "--edge-losses-only") if a in sys.argv]
+    partial = [a for a in ("--volumes-only", "--aux-losses-only", "--variants-only", "--edge-losses-only", "--wrappers-only") if a in sys.argv]
     if partial:                           # refresh one fixture file without regenerating the others
         pf = os.path.join(GOLD, "oracle_pin.json")
         pin = json.load(open(pf))["checks"] if os.path.exists(pf) else {}
@@ -383,12 +417,15 @@ def main():
             golden_variants(ref, pin)
         if "--edge-losses-only" in partial:
             golden_edge_losses(pin)
+        if "--wrappers-only" in partial:
+            golden_wrappers(ref, pin)
     else:
         golden_losses(ref, pin)
         golden_aux_losses(ref, pin)
         golden_edge_losses(pin)
         golden_models(ref, pin)
         golden_variants(ref, pin)
+        golden_wrappers(ref, pin)
         golden_volumes(ref, pin)
     verdict = {"torch": torch.__version__, "numpy": np.__version__, "all_bitwise_equal": all(pin.values()), "checks": pin}
     with open(os.path.join(GOLD, "oracle_pin.json"), "w") as f:

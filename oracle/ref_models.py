@@ -3,7 +3,7 @@
 Plain `torch.nn` restatement of the two graded networks with the reference's state_dict layout:
 
 * VGG16-BN encoder + five-stage decoder -- /root/reference/models/unetvgg.py:6-41 (decoder block),
-  :52-105 (UNetVgg), :158-213 (UNetVggInOut)
+  :52-105 (UNetVgg), :107-132 (UNetVgg256), :158-213 (UNetVggInOut), :216-265 (UNetVggTwo)
 * plain InstanceNorm U-Nets             -- /root/reference/models/unetvgg.py:268-323 (encoder block), :335-372 (center),
                                            :373-440 (UNetNaive), :443-506 (UNetWithoutCenter), :509-574 (UNetNaiveMultiOut),
                                            :576-648 (UNetLimMultiOut), :651-728 (UNetSimple), :730-813 (UNetSkip),
@@ -18,6 +18,7 @@ container).  Only tests/, bench.py's cpu_baseline leg and __graft_entry__.smoke(
 from collections import OrderedDict
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 # (first VGG feature index, conv widths) of the five encoder stages; a stage after the first opens
@@ -305,6 +306,42 @@ class RefUNetTetra(RefUNetSimple):
             d = self.dec2(torch.cat([d, c2], 1))
             outs.append(head(self.dec1(torch.cat([d, c1], 1))))
         return outs[0], outs[1]
+
+
+class RefUNetVgg256(nn.Module):
+    """unetvgg.py:107-132."""
+
+    def __init__(self):
+        super().__init__()
+        self.unetvgg = RefUNetVgg()
+
+    def forward(self, x):
+        out = self.unetvgg(F.interpolate(x, [128, 128]))
+        return nn.AdaptiveMaxPool2d(x.shape[-2:])(out)
+
+
+class RefUNetVggTwo(nn.Module):
+    """unetvgg.py:216-265."""
+
+    def __init__(self):
+        super().__init__()
+        self.unetvggl = RefUNetVgg(in_classes=1)
+        self.unetvggr = RefUNetVgg(in_classes=1)
+
+    def forward(self, x, y=None):
+        if y is not None:
+            nz = torch.nonzero(y, as_tuple=True)
+            h0, h1 = max(0, nz[1].min() - 15), min(nz[1].max() + 15, y.shape[-2])
+            w0, w1 = max(0, nz[2].min() - 15), min(nz[2].max() + 15, y.shape[-1])
+            x = x[:, :, h0:h1, w0:w1].clone()
+        hgt, wid = x.shape[-2], x.shape[-1]
+        mid = int(wid / 2)
+        ol = self.unetvggl(F.interpolate(x[..., :mid].clone(), [256, 256]))
+        orr = self.unetvggr(F.interpolate(x[..., mid:].clone(), [256, 256]))
+        out = torch.cat((nn.AdaptiveMaxPool2d([hgt, mid])(ol), nn.AdaptiveMaxPool2d([hgt, wid - mid])(orr)), dim=-1)
+        if y is not None:
+            out = F.pad(out, (w0 - 1, y.shape[-1] - w1 + 1, h0 - 1, y.shape[-2] - h1 + 1))
+        return out
 
 
 class RefDoubleConv(nn.Module):

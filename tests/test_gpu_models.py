@@ -352,3 +352,32 @@ def test_spidernet_flat_adam_and_bf16():
             assert moved == 0.0 and float(p.grad.abs().max()) == 0.0, k
         else:
             assert torch.isfinite(p).all() and (moved > 0.0 or float(p.grad.abs().max()) < 1e-12), k
+
+
+@pytest.mark.parametrize("name", ["unetvgg256", "unetvggtwo"])
+def test_resizing_wrappers_vs_golden(name):
+    """UNetVgg256 / UNetVggTwo (models/unetvgg.py:107-132, 216-265): torch re-sizing at the boundary around HIP networks;
+    logits, loss and gradient norms of one training step against the reference's vectors (tests/golden/wrappers.npz)."""
+    import os
+    import models.unetvgg as M
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from oracle.ref_models import hash_init_, synthetic_batch
+    from segk import _lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wrappers.npz"))
+    two = name == "unetvggtwo"
+    x, t = synthetic_batch(2, 96, 3, in_ch=1 if two else 3, tag=f"model:{name}")
+    model = hash_init_(M.UNetVggTwo() if two else M.UNetVgg256()).cuda().train()
+    for m in model.children():
+        m.set_compute_dtype(torch.float32)
+    before = _lib.launches
+    y = model(x.cuda(), t.cuda()) if two else model(x.cuda())
+    loss = dice_loss_sq(y, t.cuda()) + focal_loss_with_logits(y, t.cuda())
+    loss.backward()
+    assert _lib.launches - before > 100, "the HIP library did not run the networks"
+    report(f"{name}/logits", y.detach().cpu(), torch.from_numpy(g[f"{name}/logits"]), rtol=1e-4, atol=1e-4)
+    report(f"{name}/loss", loss.detach().cpu(), torch.from_numpy(g[f"{name}/loss"]), rtol=1e-4, atol=1e-6)
+    for k, p in model.named_parameters():
+        gn = float(g[f"{name}/grad_norm/{k}"])
+        if gn > 1e-6:
+            assert abs(float(p.grad.double().norm()) - gn) / gn < 2e-2, f"{k}: grad norm {float(p.grad.norm())} vs {gn}"

@@ -224,6 +224,27 @@ def test_detectmid_host_path_matches_oracle():
         assert torch.equal(b, outs[1][2][k]), k
 
 
+def test_resizing_wrappers_layout_and_host_path(tmp_path):
+    """UNetVgg256 / UNetVggTwo / UNetVggWholeImg (models/unetvgg.py:107-155, 216-265): state_dict layout of the reference,
+    and the CPU-tensor path equal to the oracle's on a small image."""
+    import models.unetvgg as M
+    from oracle import ref_models as RM
+    keys = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
+    for name, mk, mk_or in (("unetvgg256", M.UNetVgg256, RM.RefUNetVgg256), ("unetvggtwo", M.UNetVggTwo, RM.RefUNetVggTwo)):
+        sd = mk().state_dict()
+        assert list(sd.keys()) == list(keys[name].keys()) and all(list(v.shape) == keys[name][k] for k, v in sd.items())
+    torch.set_num_threads(8)
+    x, _ = RM.synthetic_batch(1, 64, 3, in_ch=3, tag="model:wrap_host")
+    a, b = RM.hash_init_(M.UNetVgg256()).eval(), RM.hash_init_(RM.RefUNetVgg256()).eval()
+    with torch.no_grad():
+        assert torch.equal(a(x[..., :40]), b(x[..., :40]))
+    ck = tmp_path / "ck.pt"
+    torch.save({"state_dict": a.unetvgg.state_dict()}, ck)
+    w = M.UNetVggWholeImg(str(ck)).eval()
+    with torch.no_grad():
+        assert torch.equal(w(x), a.unetvgg(x))
+
+
 def test_constructor_surface():
     from models.unetvgg import UNetVgg, UNetVggInOut, make_decoder_block
     from models.unetplusplus import Nested_UNet, conv_block_nested
