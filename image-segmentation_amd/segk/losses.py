@@ -147,6 +147,50 @@ def dice_coefficient(probs, act, is_list_bat=False, nosft=False, channelcnt=None
     return (kept * sel[:, None]).sum() / div
 
 
+def _dice_sums(z, labels, flags):
+    """Per-(image, class) sums of the fused forward kernel: [N, C, 4] = (sum p g, sum p^2, sum g, focal) -- with SELF_ADJ
+    (sum p g (1-p), sum p (1-p), sum g, -) -- and the per-image 'has foreground' flags."""
+    N, C = z.shape[0], z.shape[1]
+    HW = z[0, 0].numel()
+    dev, st = _env(z)
+    sums = torch.empty(N * C * 4, dtype=torch.float32, device=z.device)
+    iflags = torch.empty(N, dtype=torch.int32, device=z.device)
+    ws = workspace(query("segk_dice_focal_workspace", N, C, HW), z.device)
+    call("segk_dice_focal_fwd", z.data_ptr(), dt(z.dtype), labels.data_ptr(), None, N, C, HW, 2.0, None, flags,
+         sums.data_ptr(), iflags.data_ptr(), None, ws.data_ptr(), ws.numel(), dev, st)
+    return sums.view(N, C, 4), iflags
+
+
+def dice_coefficientold(probs, act, is_list_bat=False, nosft=False, channelcnt=None):
+    """The earlier, un-squared soft Dice (reference loss/dice.py:186-256): (2 sum p g + 1) / (sum p + sum g + 1), background
+    dropped, averaged over the images with foreground.  On CUDA scores it is a metric (no gradient): two passes of the fused
+    forward kernel give sum p = sum p^2 + sum p (1 - p)."""
+    plain = probs.dim() == 4 and probs.shape[1] > 1 and (not channelcnt or channelcnt == probs.shape[1])
+    if not probs.is_cuda or not plain:
+        if probs.is_cuda:
+            raise NotImplementedError("the HIP path takes [N,C,H,W] scores with C > 1 and [N,H,W] integer labels")
+        return _host_dice_old(probs, act, is_list_bat, nosft, channelcnt)
+    _lib.lib()
+    sq = _as_square_labels(act)
+    if sq.dtype != torch.int64:
+        raise RuntimeError("scatter(): Expected dtype int64 for index")
+    z = probs.detach().contiguous()
+    if z.dtype not in (torch.float32, torch.bfloat16):
+        z = z.float()
+    labels = sq.contiguous()
+    base = NO_SFT if nosft else 0
+    s0, iflags = _dice_sums(z, labels, base)
+    s1, _ = _dice_sums(z, labels, base | SELF_ADJ)
+    dice = (2 * s0[..., 0] + 1) / (s0[..., 1] + s1[..., 1] + s0[..., 2] + 1)
+    kept = dice[:, 1:]
+    if is_list_bat:
+        return kept
+    sel = iflags.bool()
+    nsel = sel.sum()
+    div = torch.where(nsel > 0, nsel * kept.shape[1], torch.tensor(kept.numel(), device=z.device))
+    return (kept * sel[:, None]).sum() / div
+
+
 def argmax_mask(logits):
     """uint8 arg-max mask [N,H,W] of NCHW scores (first maximum wins, like torch.argmax)."""
     _lib.lib()
@@ -176,6 +220,33 @@ def focal_loss_with_logits(p, t, gamma=2., alpha=None, reduction='elementwise_me
         return out[2].to(p.dtype)
     _, loss = dice_focal(p, t, gamma=gamma, alpha=alpha, focal_sum=(reduction == 'sum'))
     return loss.to(p.dtype)
+
+
+def reduce(to_reduce, reduction):
+    """reference loss/focal.py:5-30"""
+    if reduction == 'elementwise_mean':
+        return torch.mean(to_reduce)
+    if reduction == 'none':
+        return to_reduce
+    if reduction == 'sum':
+        return torch.sum(to_reduce)
+    raise ValueError('Reduction parameter unknown.')
+
+
+def _general_focal_loss(p, t, gamma, loss_val, alpha_weight=1., reduction='elementwise_mean'):
+    """Focal weighting of an arbitrary per-pixel loss (reference loss/focal.py:32-75): p probabilities, t one-hot target.
+    Element-wise torch glue on whatever device the tensors live on; the training path is focal_loss_with_logits, which
+    fuses softmax, cross entropy and this weighting into the HIP loss kernels."""
+    weight = (1 - torch.where(torch.eq(t, 1.), p, 1 - p)).pow(gamma)
+    if loss_val.dim() < weight.dim():
+        loss_val = loss_val.unsqueeze(1)
+    return reduce(weight * alpha_weight * loss_val, reduction)
+
+
+def _focal_loss(p, t, gamma, loss_val, reduction):
+    """reference loss/focal.py:77-106: integer labels -> one-hot, class weight 1."""
+    onehot = torch.zeros_like(p).scatter_(1, t.unsqueeze(1), 1)
+    return _general_focal_loss(p=p, t=onehot, gamma=gamma, loss_val=loss_val, reduction=reduction, alpha_weight=1.)
 
 
 # ------------------------------------------------------------------------------------ CPU tensors
@@ -300,3 +371,20 @@ def _host_focal(p, t, gamma, alpha, reduction):
     if reduction == 'none':
         return val
     raise ValueError('Reduction parameter unknown.')
+
+
+def _host_dice_old(scores, act, as_list, nosft, channelcnt):
+    act = act.view(act.shape[0], 1, act.shape[2], act.shape[2])
+    g = torch.zeros(act.shape[0], channelcnt or scores.shape[1], *act.shape[2:], device=act.device).scatter(1, act, 1)
+    if scores.dim() == 4 and scores.shape[-3] == 1:      # a [N,1,H,W] label map instead of scores
+        channelcnt = channelcnt or int(act.max()) + 1
+        p = torch.zeros(scores.shape[0], channelcnt, *scores.shape[2:], device=scores.device).scatter(1, scores.long(), 1)
+    else:
+        p = scores if nosft else scores.softmax(1)
+    table = (2 * (p * g).sum((2, 3)) + 1) / (p.sum((2, 3)) + g.sum((2, 3)) + 1)
+    kept = table[:, 1:]
+    if as_list:
+        return kept
+    rows = torch.unique(torch.nonzero(act, as_tuple=True)[0])
+    denom = len(rows) * kept.shape[1] if len(rows) else kept.numel()
+    return kept[rows].sum() / denom

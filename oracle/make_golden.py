@@ -155,6 +155,29 @@ def golden_edge_losses(pin):
     np.savez_compressed(os.path.join(GOLD, "losses_edge.npz"), **out)
 
 
+def golden_misc_losses(ref, pin):
+    """The remaining public helpers of loss/dice.py and loss/focal.py: dice_coefficientold (:186-256) and
+    _focal_loss (:77-106) on softmax probabilities with a cross-entropy map."""
+    dice_ref, focal_ref = ref["loss.dice"], ref["loss.focal"]
+    out = {}
+    for name, C, N, side, kw in loss_cases():
+        if side > 64 or kw:
+            continue
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        a, b = dice_ref.dice_coefficientold(z, t), RL.dice_coefficientold(z, t)
+        la, lb = dice_ref.dice_coefficientold(z, t, is_list_bat=True), RL.dice_coefficientold(z, t, is_list_bat=True)
+        ma = dice_ref.dice_coefficientold(z.argmax(1, keepdim=True), t, channelcnt=C)
+        mb = RL.dice_coefficientold(z.argmax(1, keepdim=True), t, channelcnt=C)
+        p = torch.softmax(z, 1)
+        ce = torch.nn.functional.cross_entropy(z, t, reduction="none")
+        fa = focal_ref._focal_loss(p=p, t=t, gamma=2.0, loss_val=ce, reduction="elementwise_mean")
+        fb = RL.focal_from_probabilities(p, t, 2.0, ce, "elementwise_mean")
+        pin[f"loss/{name}/misc"] = bool(bits_equal(a, b) and bits_equal(la, lb) and bits_equal(ma, mb) and bits_equal(fa, fb))
+        out[f"{name}/dice_old"], out[f"{name}/dice_old_list"] = a.numpy(), la.numpy()
+        out[f"{name}/dice_old_from_mask"], out[f"{name}/focal_from_probs"] = ma.numpy(), fa.numpy()
+    np.savez_compressed(os.path.join(GOLD, "losses_misc.npz"), **out)
+
+
 # ------------------------------------------------------------------------------------ models
 def model_cases(ref):
     uv, up = ref["models.unetvgg"], ref["models.unetplusplus"]
@@ -405,7 +428,7 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     ref = import_reference()
     pin = {}
-    partial = [a for a in ("--volumes-only", "--aux-losses-only", "--variants-only", "--edge-losses-only", "--wrappers-only") if a in sys.argv]
+    partial = [a for a in ("--volumes-only", "--aux-losses-only", "--variants-only", "--edge-losses-only", "--wrappers-only", "--misc-losses-only") if a in sys.argv]
     if partial:                           # refresh one fixture file without regenerating the others
         pf = os.path.join(GOLD, "oracle_pin.json")
         pin = json.load(open(pf))["checks"] if os.path.exists(pf) else {}
@@ -419,10 +442,13 @@ def main():
             golden_edge_losses(pin)
         if "--wrappers-only" in partial:
             golden_wrappers(ref, pin)
+        if "--misc-losses-only" in partial:
+            golden_misc_losses(ref, pin)
     else:
         golden_losses(ref, pin)
         golden_aux_losses(ref, pin)
         golden_edge_losses(pin)
+        golden_misc_losses(ref, pin)
         golden_models(ref, pin)
         golden_variants(ref, pin)
         golden_wrappers(ref, pin)

@@ -114,6 +114,41 @@ def focal_loss_with_logits(p, t, gamma=2., alpha=None, reduction='elementwise_me
 
 
 
+def dice_coefficientold(probs, act, is_list_bat=False, nosft=False, channelcnt=None):
+    """/root/reference/loss/dice.py:186-256: soft Dice with un-squared denominators."""
+    act = act.view(act.shape[0], 1, act.shape[2], act.shape[2])
+    hot = torch.zeros(act.shape[0], channelcnt if channelcnt else probs.shape[1], *act.shape[2:]).scatter(1, act, 1)
+    if probs.shape[-3] == 1 and probs.dim() == 4 or probs.dim() == 3:
+        if not channelcnt:
+            channelcnt = act.max() + 1
+        probs = torch.zeros(probs.shape[0], channelcnt, *probs.shape[2:]).scatter(1, probs.long(), 1)
+    elif not nosft:
+        probs = nn.Softmax2d()(probs)
+
+    def plane_sum(v):
+        return torch.sum(v.view(v.shape[0], v.shape[1], -1), dim=2)
+    dice = (2 * plane_sum(probs * hot) + 1) / (plane_sum(probs) + plane_sum(hot) + 1)
+    fg = dice[:, 1:]
+    if is_list_bat:
+        return fg
+    div_by = torch.numel(fg)
+    rows = torch.unique(torch.nonzero(act, as_tuple=True)[0])
+    if len(rows):
+        div_by = len(rows) * torch.numel(dice[0, 1:])
+    return torch.sum(fg[rows]) / div_by
+
+
+def focal_from_probabilities(p, t, gamma, loss_val, reduction):
+    """/root/reference/loss/focal.py:32-106 (_focal_loss -> _general_focal_loss with class weight 1)."""
+    onehot = torch.zeros_like(p).scatter_(1, t.unsqueeze(1), 1)
+    weight = 1 - torch.where(torch.eq(onehot, 1.), p, 1 - p)
+    weight.pow_(gamma)
+    if loss_val.dim() < weight.dim():
+        loss_val = loss_val.unsqueeze(1)
+    val = weight * 1. * loss_val
+    return {"elementwise_mean": torch.mean, "sum": torch.sum, "none": lambda v: v}[reduction](val)
+
+
 # ---------------------------------------------------------------------------------------------
 # Edge-aware Dice (/root/reference/loss/hausdorff.py:71-128, /root/reference/loss/edge_loss.py:32-55)
 # ---------------------------------------------------------------------------------------------

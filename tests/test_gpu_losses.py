@@ -203,3 +203,26 @@ def test_edge_map_operator_vs_oracle():
     report("edge_dx", outs[0][1].cpu(), a.grad.float(), rtol=1e-4, atol=1e-4 * float(a.grad.abs().max()))
     # fp32 oracle agrees with its fp64 evaluation to the same tolerance (sanity of the comparison itself)
     report("oracle32", RL.get_edg_c(x), want.detach().float(), rtol=1e-4, atol=1e-5)
+
+
+def test_unsquared_dice_metric_vs_golden():
+    """dice_coefficientold (reference loss/dice.py:186-256) from two passes of the fused forward kernel, against the
+    reference's vectors (tests/golden/losses_misc.npz)."""
+    import os
+    from oracle.cases import loss_cases
+    from loss.dice import dice_coefficientold
+    from segk import _lib
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "losses_misc.npz"))
+    for name, C, N, side, kw in loss_cases():
+        if f"{name}/dice_old" not in g.files:
+            continue
+        z, t = _inputs(name, C, N, side, kw)
+        before = _lib.launches
+        got = dice_coefficientold(z.cuda(), t.cuda())
+        assert _lib.launches - before == 2
+        report(f"{name}/dice_old", got.cpu(), torch.from_numpy(g[f"{name}/dice_old"]), rtol=1e-5, atol=1e-6)
+        report(f"{name}/dice_old_list", dice_coefficientold(z.cuda(), t.cuda(), is_list_bat=True).cpu(),
+               torch.from_numpy(g[f"{name}/dice_old_list"]), rtol=1e-5, atol=1e-6)
+        probs = torch.softmax(z, 1)
+        report(f"{name}/dice_old_nosft", dice_coefficientold(probs.cuda(), t.cuda(), nosft=True).cpu(), torch.from_numpy(g[f"{name}/dice_old"]),
+               rtol=1e-5, atol=1e-6)

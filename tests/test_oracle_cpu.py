@@ -106,6 +106,38 @@ def test_edge_dice_loss_oracle_and_host_path():
     assert get_edg_c(torch.zeros(2, 8, 8)).shape == (2, 1, 8, 8)          # label images become one plane
 
 
+def test_remaining_loss_helpers_oracle_and_host_path():
+    """dice_coefficientold (loss/dice.py:186-256) and the focal helpers (loss/focal.py:5-106): oracle bit-identical to the
+    reference's vectors, product CPU path equal to the oracle."""
+    from oracle import ref_losses as RL
+    from oracle.cases import loss_cases, make_loss_inputs
+    from loss.dice import dice_coefficientold
+    from loss.focal import _focal_loss, _general_focal_loss, reduce
+    g = np.load(os.path.join(ROOT, "tests", "golden", "losses_misc.npz"))
+    seen = 0
+    for name, C, N, side, kw in loss_cases():
+        if f"{name}/dice_old" not in g.files:
+            continue
+        seen += 1
+        z, t = make_loss_inputs(name, C, N, side, kw)
+        assert np.array_equal(RL.dice_coefficientold(z, t).numpy(), g[f"{name}/dice_old"])
+        assert np.array_equal(RL.dice_coefficientold(z, t, is_list_bat=True).numpy(), g[f"{name}/dice_old_list"])
+        report(f"{name}/dice_old host", dice_coefficientold(z, t), torch.from_numpy(g[f"{name}/dice_old"]), rtol=1e-6, atol=1e-7)
+        report(f"{name}/dice_old list host", dice_coefficientold(z, t, is_list_bat=True), torch.from_numpy(g[f"{name}/dice_old_list"]), rtol=1e-6, atol=1e-7)
+        report(f"{name}/dice_old mask host", dice_coefficientold(z.argmax(1, keepdim=True), t, channelcnt=C),
+               torch.from_numpy(g[f"{name}/dice_old_from_mask"]), rtol=1e-6, atol=1e-7)
+        p, ce = torch.softmax(z, 1), torch.nn.functional.cross_entropy(z, t, reduction="none")
+        assert np.array_equal(RL.focal_from_probabilities(p, t, 2.0, ce, "elementwise_mean").numpy(), g[f"{name}/focal_from_probs"])
+        report(f"{name}/focal host", _focal_loss(p=p, t=t, gamma=2.0, loss_val=ce, reduction="elementwise_mean"),
+               torch.from_numpy(g[f"{name}/focal_from_probs"]), rtol=1e-6, atol=1e-8)
+        hot = torch.zeros_like(p).scatter_(1, t.unsqueeze(1), 1)
+        assert _general_focal_loss(p, hot, 2.0, ce, reduction="none").shape == p.shape
+    assert seen == 4
+    assert float(reduce(torch.ones(3), "sum")) == 3.0
+    with pytest.raises(ValueError, match="Reduction parameter unknown"):
+        reduce(torch.ones(3), "bogus")
+
+
 def test_oracle_known_answers(golden):
     from oracle import ref_losses as RL
     z = torch.zeros(2, 4, 8, 8)
