@@ -119,6 +119,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="weight gradients on a second HIP stream next to the data gradients (off on the steps whose launches are event-timed)")
     args = ap.parse_args()
     if os.environ.get("SEGK_BENCH_TRACE_AFTER"):      # debugging aid: dump every thread's Python stack and exit if still running after N seconds
         import faulthandler
@@ -196,6 +198,9 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    from segk import engine
+    engine._WGRAD_STREAM = args.wgrad_stream or engine._WGRAD_STREAM
+    overlap = engine._WGRAD_STREAM
     for _ in range(args.warmup):
         step()
     barrier()
@@ -207,6 +212,7 @@ def main():
     for i in range(args.steps):
         sample = timer is not None and i % 4 == 0
         ops.CONV_TIMER = timer if sample else None
+        engine._WGRAD_STREAM = overlap and not sample     # two convolutions sharing the GPU would stretch each other's event times
         timed_steps += int(sample)
         loss = step()
     barrier()

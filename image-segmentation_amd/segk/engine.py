@@ -25,6 +25,12 @@ _WGRAD_STREAM = os.environ.get("SEGK_WGRAD_STREAM", "0") == "1"
 _side_streams = {}
 
 
+def _data_parallel():
+    """More than one rank: the side stream stays off.  Bucket all-reduces would be launched from inside it, and that
+    combination cannot be exercised where only one GPU is at hand (RCCL refuses two ranks on one device)."""
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+
 def side_stream(device, create=True):
     key = device.index if device.index is not None else torch.cuda.current_device()
     if key not in _side_streams and create:
@@ -128,7 +134,7 @@ class Runtime:
     @contextlib.contextmanager
     def side(self):
         """Run the enclosed launches on the side stream, after everything enqueued so far on the current stream."""
-        if not _WGRAD_STREAM or self.device.type != "cuda":
+        if not _WGRAD_STREAM or self.device.type != "cuda" or _data_parallel():
             yield
             return
         s = side_stream(self.device)
