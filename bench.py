@@ -114,7 +114,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="slices per GPU")
     ap.add_argument("--side", type=int, default=384)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid", "unetsimple"])
+    ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid", "unetsimple", "spidernet"])
     ap.add_argument("--depth", type=int, default=64, help="slices per volume (detectmid)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -167,6 +167,11 @@ def main():
         from models.unetvgg import UNetSimple
         model = UNetSimple(in_classes=1, out_classes=n_classes, channelscale=128)
         gflop = None                               # taken from the FLOP count the convolution launches report
+    elif args.model == "spidernet":
+        # the configuration of perlosstrain/train_percloss.py:39 (channelscale 128), logits only
+        from models.unetvgg import SpiderNet
+        model = SpiderNet(in_classes=1, out_classes=n_classes, channelscale=128)
+        gflop = None
     else:
         model = UNetVgg(out_classes=n_classes, if_convtrans=args.model == "unetvgg_convtrans")
         gflop = GFLOP_PER_SLICE if args.model == "unetvgg" else 539.05
@@ -180,7 +185,7 @@ def main():
         t = torch.randint(0, min(args.depth, 80), (args.batch,), generator=g).to(device)
     else:
         x, t = synthetic(args.batch, args.side, n_classes, device, seed=20 + rank)
-    if args.model in ("unetpp", "unetsimple"):
+    if args.model in ("unetpp", "unetsimple", "spidernet"):
         x = x[:, :1].contiguous()
 
     def step():
@@ -241,7 +246,8 @@ def main():
         out = {
             "metric": ("train volumes/sec (fwd+bwd+loss) DenseNet3D-169 DetectMid " + f"{args.depth}x{args.side}x{args.side}") if args.model == "detectmid" else
                       "train slices/sec (fwd+bwd+loss) " + {"unetvgg": "UNet-VGG", "unetvgg_convtrans": "UNet-VGG (transposed-conv decoder)",
-                                                              "unetpp": "UNet++", "unetsimple": "UNetSimple (channelscale 128)"}[args.model] + f" {args.side}x{args.side}",
+                                                              "unetpp": "UNet++", "unetsimple": "UNetSimple (channelscale 128)",
+                                                              "spidernet": "SpiderNet (channelscale 128)"}[args.model] + f" {args.side}x{args.side}",
             "value": round(value, 2), "unit": "volumes/s" if args.model == "detectmid" else "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
