@@ -60,6 +60,31 @@ __global__ __launch_bounds__(kThreads) void im2col3x3_kernel(const float* __rest
     }
 }
 
+// Same patch image, one thread per pixel, for the shapes the networks use (1-3 input channels, 32 stored columns): the
+// column -> (tap, channel) mapping is resolved at compile time and neighbouring lanes read neighbouring pixels of one plane.
+template <typename T, int CIN>
+__global__ __launch_bounds__(kThreads) void im2col3x3_pixel_kernel(const float* __restrict__ src, int64_t N, int H, int W,
+                                                                   T* __restrict__ dst, int64_t ld) {
+    const int64_t HW = (int64_t)H * W, items = N * HW;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < items; i += (int64_t)gridDim.x * kThreads) {
+        const int64_t n = i / HW;
+        const int hw = (int)(i % HW), y = hw / W, x = hw % W;
+        const float* img = src + n * CIN * HW;
+        float o[4][8];
+#pragma unroll
+        for (int k = 9 * CIN; k < 32; ++k) o[k / 8][k % 8] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) o[(tap * CIN + c) / 8][(tap * CIN + c) % 8] = ok ? img[c * HW + (int64_t)yy * W + xx] : 0.f;
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) Elem<T>::store8(dst + i * ld + v * 8, o[v]);
+    }
+}
+
 // ------------------------------------------------------------------------------ statistics
 // Block (b, g) sums its pixel range of group g for all channels.  partial layout:
 //   ws[((g*bpg + b)*2 + k)*C + c],  k = 0: sum, 1: sum of squares (or the two backward sums)
@@ -1175,6 +1200,15 @@ extern "C" int segk_im2col3x3(const float* src, int64_t N, int64_t Cin, int64_t 
     SEGK_REQUIRE(src && N > 0 && Cin > 0 && H > 0 && W > 0 && Cout >= 9 * Cin, SEGK_ESHAPE, "im2col3x3: bad shape");
     SEGK_CHECK_ACT("im2col3x3", dst, ld, Cout, dst_dtype);
     SEGK_HIP(use_device(dev));
+    if (Cout == 32 && Cin <= 3) {
+        const int g = grid_for(N * H * W);
+        hipStream_t st = (hipStream_t)stream;
+        if (Cin == 1) { SEGK_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((im2col3x3_pixel_kernel<T, 1>), dim3(g), dim3(kThreads), 0, st, src, N, (int)H, (int)W, (T*)dst, ld)); }
+        else if (Cin == 2) { SEGK_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((im2col3x3_pixel_kernel<T, 2>), dim3(g), dim3(kThreads), 0, st, src, N, (int)H, (int)W, (T*)dst, ld)); }
+        else { SEGK_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((im2col3x3_pixel_kernel<T, 3>), dim3(g), dim3(kThreads), 0, st, src, N, (int)H, (int)W, (T*)dst, ld)); }
+        SEGK_LAUNCH_CHECK();
+        return SEGK_OK;
+    }
     const int64_t items = N * H * W * (Cout / 8);
     SEGK_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((im2col3x3_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0,
                                                          (hipStream_t)stream, src, N, (int)Cin, (int)H, (int)W, (T*)dst, (int)Cout, ld));
