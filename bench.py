@@ -61,30 +61,71 @@ def detectmid_gflop(model, depth, side):
     return total / 1e9
 
 
-def cpu_baseline(n_classes, seconds_budget=25.0):
-    """The CPU oracle (plain torch.nn restatement pinned to the reference) on configs[0]: N=4, fp32, fwd+loss+bwd."""
+def host_cpu():
+    """(threads this process may use, os.cpu_count(), CPU model string).  The GPU box hands a one-GPU job a share of
+    the host's cores and says so through OMP_NUM_THREADS; os.cpu_count() there is the whole machine."""
+    total = os.cpu_count() or 1
+    share = total
+    for var in ("OMP_NUM_THREADS", "MAX_JOBS"):
+        v = os.environ.get(var, "")
+        if v.isdigit() and int(v) > 0:
+            share = min(share, int(v))
+            break
+    if hasattr(os, "sched_getaffinity"):
+        share = min(share, len(os.sched_getaffinity(0)))
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return share, total, model
+
+
+def cpu_baseline(n_classes, warmup=3, timed=10, seconds_budget=45.0):
+    """The CPU oracle (plain torch.nn restatement pinned to the reference) on configs[0]: N=4, fp32, fwd+loss+bwd, with
+    k = every core this job may use and k = 8 threads; 3 warm-up + 10 timed steps each, median (fewer timed steps only
+    if the whole leg would run past `seconds_budget`, and then the sample says how many)."""
     from oracle import ref_losses as RL
     from oracle.ref_models import RefUNetVgg
-    threads = min(16, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
+    share, total, cpu_model = host_cpu()
     torch.manual_seed(20)
     model = RefUNetVgg(out_classes=n_classes).train()
     x, t = synthetic(4, 384, n_classes, "cpu")
-    times = []
-    t_start = time.perf_counter()
-    for i in range(4):
+
+    def one():
         t0 = time.perf_counter()
         model.zero_grad()
         logits = model(x)
         loss = RL.dice_loss_sq(logits, t) + RL.focal_loss_with_logits(logits, t)
         loss.backward()
-        times.append(time.perf_counter() - t0)
-        if time.perf_counter() - t_start > seconds_budget and i >= 1:
-            break
-    steady = times[1:] if len(times) > 1 else times
-    best = sorted(steady)[len(steady) // 2]
-    return {"value": round(4 / best, 4), "unit": "slices/s", "cores": threads, "kind": "port",
-            "sample": f"oracle RefUNetVgg fp32, batch 4 x 3x384x384, fwd+loss+bwd, median of {len(steady)} steps after 1 warm-up"}
+        return time.perf_counter() - t0
+
+    runs = {}
+    ks = [share] + ([8] if share != 8 else [])
+    t_start = time.perf_counter()
+    for i, k in enumerate(ks):
+        torch.set_num_threads(k)
+        deadline = t_start + seconds_budget * (i + 1) / len(ks)
+        for _ in range(warmup):
+            one()
+        times = []
+        for _ in range(timed):
+            times.append(one())
+            if time.perf_counter() > deadline and len(times) >= 3:
+                break
+        med = sorted(times)[len(times) // 2]
+        runs[k] = {"slices_per_s": round(4 / med, 4), "threads": k, "timed_steps": len(times), "warmup_steps": warmup,
+                   "median_s_per_step": round(med, 4)}
+    main = runs[share]
+    return {"value": main["slices_per_s"], "unit": "slices/s", "cores": share, "kind": "port",
+            "sample": f"oracle RefUNetVgg fp32, batch 4 x 3x384x384, fwd+loss+bwd, median of {main['timed_steps']} timed steps after "
+                      f"{warmup} warm-up, torch.set_num_threads({share})",
+            "os_cpu_count": total, "cpu_model": cpu_model, "threads_available_to_job": share,
+            "runs": {f"k={k}": v for k, v in runs.items()}}
 
 
 def cpu_baseline_detectmid(depth, side):
@@ -106,6 +147,23 @@ def cpu_baseline_detectmid(depth, side):
             "sample": f"oracle RefDetectMid fp32, batch 2 x 1x{depth}x{side}x{side}, fwd+loss+bwd, second of 2 steps"}
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks of this script as a
+    CHILD process (this process has made no GPU call and makes none), relay its output -- rank 0's JSON line is the
+    last line on stdout -- and return its exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +175,9 @@ def main():
     ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid", "unetsimple", "spidernet"])
     ap.add_argument("--depth", type=int, default=64, help="slices per volume (detectmid)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --batch is the GLOBAL batch, split over the ranks")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher self-test: rendezvous of the N ranks on the CPU (gloo), no GPU work, prints the rank count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--wgrad-stream", action="store_true",
@@ -126,7 +187,28 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ["SEGK_BENCH_TRACE_AFTER"]), exit=True)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # before anything touches the GPU: the ranks are child processes
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                 f"(or run `python bench.py --gpus {args.gpus}` directly, which starts the ranks itself)")
+    if args.dry_run:
+        import torch.distributed as dist
+        seen = 1
+        if world > 1:
+            dist.init_process_group("gloo")
+            one = torch.ones(1)
+            dist.all_reduce(one)
+            seen = int(one.item())
+            dist.destroy_process_group()
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": seen, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        return
+    if args.strong:
+        if args.batch % world:
+            sys.exit(f"bench.py --strong: global batch {args.batch} does not divide over {world} ranks")
+        args.batch //= world
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = local % max(torch.cuda.device_count(), 1)     # rehearsals may put several ranks on one card (gloo only)
@@ -228,6 +310,24 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
     final_loss = float(loss.detach())
+    # second number: forward + loss + backward (+ all-reduce) only, no optimizer step
+    k2 = max(3, min(10, args.steps))
+    engine._WGRAD_STREAM = overlap
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(k2):
+        lg = model(x)
+        if args.model == "detectmid":
+            l2 = torch.nn.functional.cross_entropy(lg, t)
+        else:
+            l2 = dice_loss_sq(lg, t) + focal_loss_with_logits(lg, t)
+        l2.backward()
+    barrier()
+    no_opt = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([no_opt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        no_opt = float(tt)
     # host -> device copy of one batch from pinned memory (informational: never part of `value`, inputs are resident)
     hx, ht = x.detach().cpu().pin_memory(), t.cpu().pin_memory()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -250,13 +350,16 @@ def main():
                                                               "spidernet": "SpiderNet (channelscale 128)"}[args.model] + f" {args.side}x{args.side}",
             "value": round(value, 2), "unit": "volumes/s" if args.model == "detectmid" else "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"detectmid {args.depth}x{args.side}x{args.side}, 80 classes, {args.batch} volumes/GPU, fwd + cross entropy + bwd + "
                                     if args.model == "detectmid" else
                                     f"{args.model} {args.side}x{args.side}, {n_classes} classes, {args.batch} slices/GPU, fwd + fused Dice/focal loss + bwd + ")
                                    + f"{'bucketed RCCL all-reduce + ' if world > 1 else ''}fused Adam",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "random_init_weights": True,
                        "final_loss": round(final_loss, 5), "h2d_ms_per_batch": round(h2d_ms, 3),
+                       "slices_per_s_without_optimizer_step": round(world * args.batch * k2 / no_opt, 2),
+                       "collective": (f"{torch.distributed.get_backend()} all-reduce, {torch.distributed.get_world_size()} ranks, "
+                                      f"{len(flat.buckets.ranges)} buckets") if world > 1 else None,
                        "value_if_h2d_not_overlapped": round(world * args.batch * args.steps / (elapsed + args.steps * h2d_ms / 1e3), 2)},
         }
         if timer:

@@ -35,8 +35,29 @@ static inline size_t esize(int dtype) { return dtype == SEGK_BF16 ? 2 : 4; }
 static inline bool is_pow2(int64_t v) { return v > 0 && (v & (v - 1)) == 0; }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-// Select the device for this host thread (autograd's backward runs on another thread than forward).
-static inline hipError_t use_device(int dev) { return hipSetDevice(dev); }
+// Make `dev` the calling thread's HIP device for the duration of an entry point (autograd's backward runs on another
+// host thread than forward, and a tensor may live on a device other than the thread's current one); the previous
+// device is restored on return, so the library leaves the caller's (and PyTorch's) notion of "current device" alone.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int dev) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != dev) {
+            err = hipSetDevice(dev);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define SEGK_USE_DEVICE(dev)             \
+    segk::DeviceGuard device_guard_(dev); \
+    SEGK_HIP(device_guard_.err)
 
 // Error check after a launch without synchronising.
 #define SEGK_LAUNCH_CHECK() SEGK_HIP(hipGetLastError())

@@ -1031,7 +1031,7 @@ extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, in
     SEGK_REQUIRE(Cout > 0 && Cin > 0 && seg0 >= 0 && seg0 <= Cin, SEGK_ESHAPE, "conv_pack: bad channel counts (Cout=%lld Cin=%lld seg0=%lld)",
                  (long long)Cout, (long long)Cin, (long long)seg0);
     SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "conv_pack: packed buffers must be 16-byte aligned");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     if (seg0 == 0) seg0 = Cin;
     const int64_t kf = round_up(seg0, kr) + round_up(Cin - seg0, kr);
@@ -1047,7 +1047,7 @@ extern "C" int segk_conv_pack(const float* w_oihw, int64_t Cout, int64_t Cin, in
 extern "C" int segk_conv_pack_batch(int dtype, const segk_pack_desc* descs_dev, int64_t n, int64_t blocks_per_desc, int dev, void* stream) {
     SEGK_REQUIRE(descs_dev && n > 0 && n < 65536 && blocks_per_desc > 0 && blocks_per_desc <= 1024, SEGK_EINVAL, "conv_pack_batch: bad arguments");
     SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "conv_pack_batch: unknown dtype");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((conv_pack_batch_kernel<T>), dim3((unsigned)blocks_per_desc, (unsigned)n), dim3(kConvThreads), 0,
                                                      (hipStream_t)stream, descs_dev));
     SEGK_LAUNCH_CHECK();
@@ -1073,7 +1073,7 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
                  "conv_fwd: mask_channels must be a multiple of 8 in (0, Cout] and fit ld_mask");
     SEGK_REQUIRE(!stat_partials || (aligned16(stat_partials) && !y1 && !mask && !(flags & 6)), SEGK_EINVAL,
                  "conv_fwd: output statistics need a single destination, no mask, no accumulation and a 16-byte aligned buffer");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     ConvArgs a;
     a.stat_part = stat_partials;
@@ -1128,7 +1128,7 @@ extern "C" int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0,
                  SEGK_ESHAPE, "conv_wgrad: bad channel counts (Cout=%lld cin_real=%lld)", (long long)Cout, (long long)cin_real);
     SEGK_REQUIRE(aligned16(dy) && (ldy * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_wgrad: dy pointer/ld misaligned");
     SEGK_REQUIRE(workspace_bytes >= segk_conv_wgrad_workspace(dtype, taps, C0, C1, N, H, W, Cout), SEGK_EWORKSPACE, "conv_wgrad: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     WgradArgs a;
     a.x0 = (const char*)x0; a.x1 = (const char*)x1; a.ld0 = ld0; a.ld1 = ld1;
@@ -1180,7 +1180,7 @@ extern "C" int segk_convt_pack(const float* w, int64_t Cin, int64_t Cout, int dt
     SEGK_REQUIRE(w && (wf || wb) && Cin > 0 && Cout > 0, SEGK_EINVAL, "convt_pack: bad arguments");
     SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "convt_pack: unknown dtype");
     SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "convt_pack: packed buffers must be 16-byte aligned");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t slots = (int64_t)((wf ? 4 * convt_phase_bytes(dtype, Cin, Cout, true) : 0) + (wb ? 4 * convt_phase_bytes(dtype, Cin, Cout, false) : 0)) / 16;
     int64_t grid = (slots + kConvThreads - 1) / kConvThreads;
     if (grid > 4096) grid = 4096;
@@ -1196,7 +1196,7 @@ extern "C" int segk_convt_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin
     if (int rc = check_convt("convt_fwd(y)", dtype, y, ldy, Cout)) return rc;
     SEGK_REQUIRE(wf && aligned16(wf) && N > 0 && H > 0 && W > 0 && N * H * W * 4 < (1ll << 28), SEGK_ESHAPE, "convt_fwd: bad arguments");
     SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "convt_fwd: bias must be 16-byte aligned");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     ConvArgs a;
     a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
@@ -1224,7 +1224,7 @@ extern "C" int segk_convt_dgrad(int dtype, const void* dy, int64_t ld_dy, int64_
     if (int rc = check_convt("convt_dgrad(dx)", dtype, dx, ld_dx, Cin)) return rc;
     SEGK_REQUIRE(wb && aligned16(wb) && N > 0 && H > 0 && W > 0 && N * H * W * 4 < (1ll << 28), SEGK_ESHAPE, "convt_dgrad: bad arguments");
     SEGK_REQUIRE(!mask || (aligned16(mask) && ld_mask >= Cin && (ld_mask * esize(dtype)) % 16 == 0), SEGK_EALIGN, "convt_dgrad: mask misaligned");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     ConvArgs a;
     a.x0 = (const char*)dy; a.x1 = nullptr; a.ld0 = ld_dy; a.ld1 = 0; a.C0 = (int)Cout; a.C1 = 0;
@@ -1258,7 +1258,7 @@ extern "C" int segk_convt_wgrad(int dtype, const void* x, int64_t ldx, int64_t C
     if (int rc = check_convt("convt_wgrad(dy)", dtype, dy, ld_dy, Cout)) return rc;
     SEGK_REQUIRE(dw && workspace && N > 0 && H > 0 && W > 0 && N * H * W * 4 < (1ll << 28), SEGK_ESHAPE, "convt_wgrad: bad arguments");
     SEGK_REQUIRE(workspace_bytes >= segk_convt_wgrad_workspace(dtype, Cin, Cout, N, H, W), SEGK_EWORKSPACE, "convt_wgrad: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a;
@@ -1314,7 +1314,7 @@ extern "C" int segk_conv3d_pack(const float* w, int64_t Cout, int64_t Cin, int d
     SEGK_REQUIRE(w && (wf || wb) && Cin > 0 && Cout > 0, SEGK_EINVAL, "conv3d_pack: bad arguments");
     SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "conv3d_pack: unknown dtype");
     SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "conv3d_pack: packed buffers must be 16-byte aligned");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     const size_t per_f = conv3d_image_bytes(dtype, Cout, Cin, true), per_b = conv3d_image_bytes(dtype, Cout, Cin, false);
     const int64_t slots = ((wf ? round_up(Cin, kr) / kr * round_up(Cout, 32) : 0) + (wb ? round_up(Cout, kr) / kr * round_up(Cin, 32) : 0)) * 9 * 8;
@@ -1337,7 +1337,7 @@ extern "C" int segk_conv3d_fwd(int dtype, const void* x, int64_t ldx, int64_t Ci
     if (int rc = check_convt("conv3d_fwd(y)", dtype, y, ldy, Cout)) return rc;
     SEGK_REQUIRE(w_packed && aligned16(w_packed) && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28), SEGK_ESHAPE,
                  "conv3d_fwd: bad arguments");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     ConvArgs a;
     a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
@@ -1382,7 +1382,7 @@ extern "C" int segk_conv3d_wgrad(int dtype, const void* x, int64_t ldx, int64_t 
     if (int rc = check_convt("conv3d_wgrad(dy)", dtype, dy, ld_dy, Cout)) return rc;
     SEGK_REQUIRE(dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28), SEGK_ESHAPE, "conv3d_wgrad: bad arguments");
     SEGK_REQUIRE(workspace_bytes >= segk_conv3d_wgrad_workspace(dtype, Cin, N, D, H, W, Cout), SEGK_EWORKSPACE, "conv3d_wgrad: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a;
@@ -1440,7 +1440,7 @@ extern "C" int segk_convd_pack(const float* w, int64_t Cout, int64_t Cin, int64_
     if (int rc = check_convd("convd_pack", kd)) return rc;
     SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "convd_pack: unknown dtype");
     SEGK_REQUIRE((!wf || aligned16(wf)) && (!wb || aligned16(wb)), SEGK_EALIGN, "convd_pack: packed buffers must be 16-byte aligned");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     const size_t per_f = convd_image_bytes(dtype, Cout, Cin, true), per_b = convd_image_bytes(dtype, Cout, Cin, false);
     const int64_t slots = ((wf ? round_up(Cin, kr) / kr * round_up(Cout, 32) : 0) + (wb ? round_up(Cout, kr) / kr * round_up(Cin, 32) : 0)) * 8;
@@ -1466,7 +1466,7 @@ extern "C" int segk_convd_fwd(int dtype, const void* x, int64_t ldx, int64_t Cin
     SEGK_REQUIRE(w_packed && aligned16(w_packed) && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28), SEGK_ESHAPE,
                  "convd_fwd: bad arguments");
     SEGK_REQUIRE(!stat_partials || (aligned16(stat_partials) && !(flags & 2)), SEGK_EINVAL, "convd_fwd: statistics need a non-accumulating call");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     ConvArgs a;
     a.x0 = (const char*)x; a.x1 = nullptr; a.ld0 = ldx; a.ld1 = 0; a.C0 = (int)Cin; a.C1 = 0;
@@ -1507,7 +1507,7 @@ extern "C" int segk_convd_wgrad(int dtype, const void* x, int64_t ldx, int64_t C
     SEGK_REQUIRE(dw && workspace && N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 28) && cin_real > 0 && cin_real <= Cin,
                  SEGK_ESHAPE, "convd_wgrad: bad arguments");
     SEGK_REQUIRE(workspace_bytes >= segk_convd_wgrad_workspace(dtype, Cin, N, D, H, W, Cout, kd), SEGK_EWORKSPACE, "convd_wgrad: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int kr = krow(dtype);
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a;

@@ -188,7 +188,7 @@ extern "C" int segk_edge_fwd(const float* x, int64_t planes, int64_t H, int64_t 
                              void* workspace, size_t workspace_bytes, int dev, void* stream) {
     if (int rc = edge_check("edge_fwd", x, planes, H, W, workspace, workspace_bytes)) return rc;
     SEGK_REQUIRE(edge && stats, SEGK_EINVAL, "edge_fwd: null pointer");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int splits = edge_splits(planes, H * W);
     const dim3 grid(splits, (unsigned)planes);
@@ -207,7 +207,7 @@ extern "C" int segk_edge_bwd(const float* x, const float* dedge, const float* st
     if (int rc = edge_check("edge_bwd", x, planes, H, W, workspace, workspace_bytes)) return rc;
     SEGK_REQUIRE(dedge && stats && dx, SEGK_EINVAL, "edge_bwd: null pointer");
     SEGK_REQUIRE(workspace_bytes >= segk_edge_bwd_workspace(planes, H, W), SEGK_EWORKSPACE, "edge_bwd: workspace %zu too small", workspace_bytes);
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int splits = edge_splits(planes, H * W);
     const dim3 grid(splits, (unsigned)planes);

@@ -426,7 +426,7 @@ extern "C" int segk_dice_focal_fwd(const void* logits, int logits_dtype, const i
     SEGK_REQUIRE(N > 0 && HW > 0 && N < 65536, SEGK_ESHAPE, "dice_focal_fwd: bad N=%lld HW=%lld", (long long)N, (long long)HW);
     SEGK_REQUIRE(workspace_bytes >= segk_dice_focal_workspace(N, C, HW), SEGK_EWORKSPACE, "dice_focal_fwd: workspace %zu too small", workspace_bytes);
     SEGK_REQUIRE(!focal_map || labels, SEGK_EINVAL, "dice_focal_fwd: focal map needs integer labels");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int bpi = loss_bpi(N, HW);
     SEGK_DISPATCH_C(C, SEGK_DISPATCH_DTYPE(logits_dtype, TL, (launch_fwd<TL, CC>(logits, labels, hot, N, HW, gamma, alpha, flags,
@@ -442,7 +442,7 @@ extern "C" int segk_dice_focal_finalize(const float* sums, const int32_t* img_fl
                                         int flags, float* out_scalars, int dev, void* stream) {
     SEGK_REQUIRE(sums && img_flags && out_scalars, SEGK_EINVAL, "dice_focal_finalize: null pointer");
     SEGK_REQUIRE(N > 0 && C > 0 && C <= kMaxC && HW > 0, SEGK_ESHAPE, "dice_focal_finalize: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipLaunchKernelGGL(dice_focal_finalize_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, img_flags, (int)N, (int)C,
                        HW, (flags >> 1) & 1, (flags >> 2) & 1, out_scalars);
     SEGK_LAUNCH_CHECK();
@@ -456,7 +456,7 @@ extern "C" int segk_dice_focal_bwd(const void* logits, int logits_dtype, const i
     SEGK_REQUIRE(logits && sums && img_flags && scalars && gscale && dlogits, SEGK_EINVAL, "dice_focal_bwd: null pointer");
     SEGK_REQUIRE((labels != nullptr) != (hot != nullptr), SEGK_EINVAL, "dice_focal_bwd: exactly one of labels/hot");
     SEGK_REQUIRE(N > 0 && HW > 0 && N < 65536, SEGK_ESHAPE, "dice_focal_bwd: bad N/HW");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int bpi = loss_bpi(N, HW);
     SEGK_DISPATCH_C(C, SEGK_DISPATCH_DTYPE(logits_dtype, TL, (launch_bwd<TL, CC>(logits, labels, hot, N, HW, gamma, alpha, flags, sums,
@@ -469,7 +469,7 @@ extern "C" int segk_argmax_dice(const void* logits, int logits_dtype, const int6
                                 int64_t HW, uint8_t* mask, float* counts, int32_t* out_flags, int dev, void* stream) {
     SEGK_REQUIRE(logits && labels && counts && out_flags, SEGK_EINVAL, "argmax_dice: null pointer");
     SEGK_REQUIRE(N > 0 && HW > 0, SEGK_ESHAPE, "argmax_dice: bad N/HW");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     SEGK_DISPATCH_C(C, SEGK_DISPATCH_DTYPE(logits_dtype, TL,
                                            hipLaunchKernelGGL((argmax_dice_kernel<TL, CC>), dim3((unsigned)N), dim3(kLossThreads), 0, st,

@@ -1187,7 +1187,7 @@ extern "C" int segk_nchw_to_nhwc(const float* src, int64_t N, int64_t Cin, int64
                                  int64_t Cout, int64_t ld, int dev, void* stream) {
     SEGK_REQUIRE(src && N > 0 && Cin > 0 && H > 0 && W > 0 && Cout >= Cin, SEGK_ESHAPE, "nchw_to_nhwc: bad shape");
     SEGK_CHECK_ACT("nchw_to_nhwc", dst, ld, Cout, dst_dtype);
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t items = N * H * W * (Cout / 8);
     SEGK_DISPATCH_DTYPE(dst_dtype, T, hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0,
                                                          (hipStream_t)stream, src, N, (int)Cin, H * W, (T*)dst, (int)Cout, ld));
@@ -1199,7 +1199,7 @@ extern "C" int segk_im2col3x3(const float* src, int64_t N, int64_t Cin, int64_t 
                               int64_t Cout, int64_t ld, int dev, void* stream) {
     SEGK_REQUIRE(src && N > 0 && Cin > 0 && H > 0 && W > 0 && Cout >= 9 * Cin, SEGK_ESHAPE, "im2col3x3: bad shape");
     SEGK_CHECK_ACT("im2col3x3", dst, ld, Cout, dst_dtype);
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     if (Cout == 32 && Cin <= 3) {
         const int g = grid_for(N * H * W);
         hipStream_t st = (hipStream_t)stream;
@@ -1232,7 +1232,7 @@ extern "C" int segk_norm_stats(int dtype, const void* x, int64_t ld, int64_t gro
     SEGK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SEGK_EINVAL, "norm_stats: running buffers come in pairs");
     SEGK_REQUIRE(!running_mean || groups == 1, SEGK_EINVAL, "norm_stats: running buffers need groups == 1");
     SEGK_REQUIRE(workspace_bytes >= segk_norm_workspace(groups, M, C), SEGK_EWORKSPACE, "norm_stats: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int bpg = stats_bpg(groups, M, C);
     // the per-(group, channel) shift lives in the second workspace section (the backward's reduced sums use it later)
@@ -1259,7 +1259,7 @@ extern "C" int segk_norm_stats_finalize(const float* partials, int64_t groups, i
     SEGK_REQUIRE(C % 8 == 0 && 2 * C / 8 <= kThreads && aligned16(partials), SEGK_ESHAPE, "norm_stats_finalize: C must be a multiple of 8, at most 1024");
     SEGK_REQUIRE((running_mean == nullptr) == (running_var == nullptr), SEGK_EINVAL, "norm_stats_finalize: running buffers come in pairs");
     SEGK_REQUIRE(!running_mean || groups == 1, SEGK_EINVAL, "norm_stats_finalize: running buffers need groups == 1");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     if (rows_per_group <= 128) {
         hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st, partials, (int)rows_per_group, M,
@@ -1285,7 +1285,7 @@ extern "C" int segk_norm_stats_finalize(const float* partials, int64_t groups, i
 extern "C" int segk_norm_eval_stats(const float* running_mean, const float* running_var, int64_t C, float eps, float* stats,
                                     int dev, void* stream) {
     SEGK_REQUIRE(running_mean && running_var && stats && C > 0, SEGK_EINVAL, "norm_eval_stats: bad arguments");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipLaunchKernelGGL(eval_stats_kernel, dim3((unsigned)((C + kThreads - 1) / kThreads)), dim3(kThreads), 0, (hipStream_t)stream,
                        running_mean, running_var, (int)C, eps, stats);
     SEGK_LAUNCH_CHECK();
@@ -1298,7 +1298,7 @@ extern "C" int segk_norm_apply(int dtype, const void* x, int64_t ldx, int64_t gr
     SEGK_CHECK_ACT("norm_apply(y)", y, ldy, C, dtype);
     if (int rc = check_norm_c("norm_apply", C)) return rc;
     SEGK_REQUIRE(stats && groups > 0 && groups < 65536 && M > 0, SEGK_EINVAL, "norm_apply: bad arguments");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(M, rows, groups);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_apply_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0,
@@ -1320,7 +1320,7 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
     SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "norm_bwd: dgamma/dbeta come in pairs");
     SEGK_REQUIRE(!dgamma || groups == 1, SEGK_EINVAL, "norm_bwd: affine gradients need groups == 1");
     SEGK_REQUIRE(workspace_bytes >= segk_norm_workspace(groups, M, C), SEGK_EWORKSPACE, "norm_bwd: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int bpg = stats_bpg(groups, M, C);
     const int relu = flags & 1, accumulate = (flags >> 1) & 1, frozen = (flags >> 2) & 1;
@@ -1356,7 +1356,7 @@ extern "C" int segk_norm_pool_apply(int dtype, const void* x, int64_t ldx, int64
     if (int rc = check_norm_c("norm_pool_apply", C)) return rc;
     SEGK_REQUIRE(stats && N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SEGK_ESHAPE,
                  "norm_pool_apply: H and W must be even (H=%lld W=%lld)", (long long)H, (long long)W);
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t Q = N * (H / 2) * (W / 2);
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(Q, rows, 1);
@@ -1381,7 +1381,7 @@ extern "C" int segk_norm_pool_bwd(int dtype, const void* dy, int64_t ld_dy, cons
     SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "norm_pool_bwd: dgamma/dbeta come in pairs");
     const int64_t M = N * H * W, Q = M / 4;
     SEGK_REQUIRE(workspace_bytes >= segk_norm_workspace(1, M, C), SEGK_EWORKSPACE, "norm_pool_bwd: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int bpg = stats_bpg(1, Q, C);
     const int accumulate = (flags >> 1) & 1, frozen = (flags >> 2) & 1;
@@ -1408,7 +1408,7 @@ extern "C" int segk_maxpool2x2_fwd(int dtype, const void* x, int64_t ldx, int64_
     SEGK_CHECK_ACT("maxpool_fwd(x)", x, ldx, C, dtype);
     SEGK_CHECK_ACT("maxpool_fwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SEGK_ESHAPE, "maxpool_fwd: H and W must be even (H=%lld W=%lld)", (long long)H, (long long)W);
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t items = N * (H / 2) * (W / 2) * (C / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
                                                      (const T*)x, ldx, N, (int)H, (int)W, (int)C, (T*)y, ldy));
@@ -1422,7 +1422,7 @@ extern "C" int segk_maxpool2x2_bwd(int dtype, const void* x, int64_t ldx, const 
     SEGK_CHECK_ACT("maxpool_bwd(dy)", dy, ld_dy, C, dtype);
     SEGK_CHECK_ACT("maxpool_bwd(dx)", dx, ld_dx, C, dtype);
     SEGK_REQUIRE(N > 0 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, SEGK_ESHAPE, "maxpool_bwd: H and W must be even");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t items = N * (H / 2) * (W / 2) * (C / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(items)), dim3(kThreads), 0, (hipStream_t)stream,
                                                      (const T*)x, ldx, (const T*)dy, ld_dy, N, (int)H, (int)W, (int)C, (T*)dx, ld_dx,
@@ -1436,7 +1436,7 @@ extern "C" int segk_upsample2x_fwd(int dtype, const void* x, int64_t ldx, int64_
     SEGK_CHECK_ACT("upsample_fwd(x)", x, ldx, C, dtype);
     SEGK_CHECK_ACT("upsample_fwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0, SEGK_ESHAPE, "upsample_fwd: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     if (!((flags >> 2) & 1)) {
         SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_half_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads),
                                                          0, (hipStream_t)stream, (const T*)x, ldx, (int)H, (int)W, (int)C, stats,
@@ -1457,7 +1457,7 @@ extern "C" int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, con
     SEGK_CHECK_ACT("upsample_bwd(dx)", dx, ld_dx, C, dtype);
     if (flags & 1) SEGK_CHECK_ACT("upsample_bwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0, SEGK_ESHAPE, "upsample_bwd: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     if (!((flags >> 2) & 1)) {
         SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_half_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
                                                          (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, (int)H, (int)W,
@@ -1478,7 +1478,7 @@ extern "C" int segk_resize_bilinear_fwd(int dtype, const void* x, int64_t ldx, i
     SEGK_CHECK_ACT("resize_fwd(x)", x, ldx, C, dtype);
     SEGK_CHECK_ACT("resize_fwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && ratio_h > 0.f && ratio_w > 0.f, SEGK_ESHAPE, "resize_fwd: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resize_fwd_kernel<T>), dim3((unsigned)patch_blocks(N, Ho, Wo, C)), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)x, ldx, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, ratio_h,
                                                      ratio_w, stats, flags & 1, (T*)y, ldy));
@@ -1492,7 +1492,7 @@ extern "C" int segk_resize_bilinear_bwd(int dtype, const void* dy, int64_t ld_dy
     SEGK_CHECK_ACT("resize_bwd(dy)", dy, ld_dy, C, dtype);
     SEGK_CHECK_ACT("resize_bwd(dx)", dx, ld_dx, C, dtype);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && ratio_h > 0.f && ratio_w > 0.f, SEGK_ESHAPE, "resize_bwd: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((resize_bwd_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)dy, ld_dy, (int)H, (int)W, (int)C, (int)Ho, (int)Wo, ratio_h,
                                                      ratio_w, (T*)dx, ld_dx, (flags >> 1) & 1));
@@ -1511,7 +1511,7 @@ extern "C" int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int6
     if (int rc = check_norm_c("colsum", C)) return rc;
     SEGK_REQUIRE(out && workspace && P > 0, SEGK_EINVAL, "colsum: bad arguments");
     SEGK_REQUIRE(workspace_bytes >= segk_colsum_workspace(P, C), SEGK_EWORKSPACE, "colsum: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int bpg = stats_bpg(1, P, C);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((stats_partial_kernel<T, 1>), dim3(bpg, 1), dim3(kThreads), 0, st, (const T*)x, ld, P,
@@ -1528,7 +1528,7 @@ extern "C" int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void*
     SEGK_CHECK_ACT("copy_slice(src)", src, ld_src, C, dtype);
     SEGK_CHECK_ACT("copy_slice(dst)", dst, ld_dst, C, dtype);
     SEGK_REQUIRE(P > 0, SEGK_ESHAPE, "copy_slice: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((copy_slice_kernel<T>), dim3(grid_for(P * (C / 8))), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)src, ld_src, (T*)dst, ld_dst, P, (int)C, (flags >> 1) & 1));
     SEGK_LAUNCH_CHECK();
@@ -1541,7 +1541,7 @@ extern "C" int segk_block2(int dtype, void* x, int64_t ldx, void* wide, int64_t 
     SEGK_CHECK_ACT("block2(wide)", wide, ld_wide, 4 * C, dtype);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && H < (1 << 20) && W < (1 << 20), SEGK_ESHAPE,
                  "block2: H and W must be even (got %lldx%lld)", (long long)H, (long long)W);
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((block2_kernel<T>), dim3(grid_for(N * H * W * (C / 8))), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (T*)x, ldx, (T*)wide, ld_wide, N, (int)(H / 2), (int)(W / 2), (int)C,
                                                      (flags & 1) ? 0 : 1, (flags >> 1) & 1));
@@ -1554,7 +1554,7 @@ extern "C" int segk_head1x1_fwd(int dtype, const void* x, int64_t ld, int64_t Ci
     SEGK_CHECK_ACT("head1x1_fwd", x, ld, Cin, dtype);
     SEGK_REQUIRE(w && logits && N > 0 && HW > 0, SEGK_EINVAL, "head1x1_fwd: bad arguments");
     SEGK_REQUIRE(Cout >= 1 && Cout <= kHeadMaxOut && Cin <= 1024, SEGK_ESHAPE, "head1x1_fwd: Cout must be 1..8 (got %lld)", (long long)Cout);
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const size_t smem = (size_t)(Cout * Cin + Cout) * sizeof(float);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid_for(N * HW, 4096)), dim3(kThreads), smem,
                                                      (hipStream_t)stream, (const T*)x, ld, (int)Cin, N, HW, w, bias, (int)Cout, logits));
@@ -1593,7 +1593,7 @@ extern "C" int segk_head1x1_bwd(int dtype, const void* x, int64_t ld, int64_t Ci
     SEGK_REQUIRE(w && dlogits && dw && workspace && N > 0 && HW > 0, SEGK_EINVAL, "head1x1_bwd: bad arguments");
     SEGK_REQUIRE(Cin == 8 || Cin == 16 || Cin == 32 || Cin == 64, SEGK_ESHAPE, "head1x1_bwd: Cin must be 8, 16, 32 or 64 (got %lld)", (long long)Cin);
     SEGK_REQUIRE(workspace_bytes >= segk_head1x1_bwd_workspace(Cin, Cout, N, HW), SEGK_EWORKSPACE, "head1x1_bwd: workspace too small");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     hipStream_t st = (hipStream_t)stream;
     const int nb = head_bwd_blocks(Cin, N, HW);
     int rc = SEGK_OK;
@@ -1611,7 +1611,7 @@ extern "C" int segk_head1x1_bwd(int dtype, const void* x, int64_t ld, int64_t Ci
 extern "C" int segk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int64_t step, float grad_scale, int dev, void* stream) {
     SEGK_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step > 0, SEGK_EINVAL, "adam_step: bad arguments");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4096)), dim3(kThreads), 0, (hipStream_t)stream, param, grad, exp_avg, exp_avg_sq, n,
@@ -1626,7 +1626,7 @@ extern "C" int segk_relu_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
     SEGK_CHECK_ACT("relu_bwd(y)", y, ldy, C, dtype);
     SEGK_CHECK_ACT("relu_bwd(dx)", dx, ld_dx, C, dtype);
     SEGK_REQUIRE(P > 0, SEGK_ESHAPE, "relu_bwd: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((relu_bwd_kernel<T>), dim3(grid_for(P * (C / 8))), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, P, (int)C, (T*)dx, ld_dx));
     SEGK_LAUNCH_CHECK();

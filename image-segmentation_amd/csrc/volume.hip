@@ -331,7 +331,7 @@ extern "C" int segk_im2col3d(int dtype, const void* x, int64_t ldx, int64_t C, i
     SEGK_CHECK_VOL("im2col3d(patches)", patches, ld_patches, Kp, dtype);
     SEGK_REQUIRE(Kp >= C * g.kd * g.kh * g.kw && Kp <= 8192, SEGK_ESHAPE, "im2col3d: Kp %lld must cover C*kd*kh*kw and be at most 8192", (long long)Kp);
     SEGK_REQUIRE(g.kd < 128 && g.kh < 256 && g.kw < 256, SEGK_ESHAPE, "im2col3d: kernel extent too large");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t items = (int64_t)g.N * g.Do * g.Ho * g.Wo * (Kp / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((im2col3d_kernel<T>), dim3(vgrid(items, 16384)), dim3(kVThreads), (size_t)Kp * sizeof(int), (hipStream_t)stream,
                                                      (const T*)x, ldx, g, (T*)patches, ld_patches, (int)Kp));
@@ -346,7 +346,7 @@ extern "C" int segk_col2im3d(int dtype, const void* dpatches, int64_t ld_patches
     if (int rc = make_geo("col2im3d", N, C, D, H, W, kernel, stride, pad, &g)) return rc;
     SEGK_CHECK_VOL("col2im3d(dx)", dx, ld_dx, 8, dtype);
     SEGK_REQUIRE(dpatches && ld_patches >= C * g.kd * g.kh * g.kw, SEGK_ESHAPE, "col2im3d: bad patch gradient");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t items = (int64_t)g.N * g.D * g.H * g.W;
     // taps per axis that can reach one voxel: ceil(kernel / stride) over the two inner axes
     const int th = (g.kh + g.sh - 1) / g.sh, tw = (g.kw + g.sw - 1) / g.sw, mt = th > tw ? th : tw;
@@ -367,7 +367,7 @@ extern "C" int segk_maxpool3d_fwd(int dtype, const void* x, int64_t ldx, int64_t
     SEGK_CHECK_VOL("maxpool3d_fwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(argmax && (reinterpret_cast<uintptr_t>(argmax) & 7u) == 0, SEGK_EALIGN, "maxpool3d_fwd: argmax must be 8-byte aligned");
     SEGK_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 31), SEGK_ESHAPE, "maxpool3d_fwd: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int Do = (int)((D - 1) / 2 + 1), Ho = (int)((H - 1) / 2 + 1), Wo = (int)((W - 1) / 2 + 1);
     const int64_t items = N * Do * Ho * Wo * (C / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool3d_fwd_kernel<T>), dim3(vgrid(items)), dim3(kVThreads), 0, (hipStream_t)stream,
@@ -382,7 +382,7 @@ extern "C" int segk_maxpool3d_bwd(int dtype, const void* dy, int64_t ld_dy, cons
     SEGK_CHECK_VOL("maxpool3d_bwd(dx)", dx, ld_dx, C, dtype);
     SEGK_REQUIRE(argmax && (reinterpret_cast<uintptr_t>(argmax) & 7u) == 0, SEGK_EALIGN, "maxpool3d_bwd: argmax must be 8-byte aligned");
     SEGK_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && N * D * H * W < (1ll << 31), SEGK_ESHAPE, "maxpool3d_bwd: bad shape");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int Do = (int)((D - 1) / 2 + 1), Ho = (int)((H - 1) / 2 + 1), Wo = (int)((W - 1) / 2 + 1);
     const int64_t items = N * D * H * W * (C / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((maxpool3d_bwd_kernel<T>), dim3(vgrid(items)), dim3(kVThreads), 0, (hipStream_t)stream,
@@ -397,7 +397,7 @@ extern "C" int segk_avgpool3d_fwd(int dtype, const void* x, int64_t ldx, int64_t
     SEGK_CHECK_VOL("avgpool3d_fwd(x)", x, ldx, C, dtype);
     SEGK_CHECK_VOL("avgpool3d_fwd(y)", y, ldy, C, dtype);
     SEGK_REQUIRE(N > 0 && D >= 2 && H >= 2 && W >= 2 && N * D * H * W < (1ll << 31), SEGK_ESHAPE, "avgpool3d_fwd: every extent must be >= 2");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t items = N * (D / 2) * (H / 2) * (W / 2) * (C / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((avgpool3d_fwd_kernel<T>), dim3(vgrid(items)), dim3(kVThreads), 0, (hipStream_t)stream,
                                                      (const T*)x, ldx, N, (int)D, (int)H, (int)W, (int)C, (T*)y, ldy));
@@ -410,7 +410,7 @@ extern "C" int segk_avgpool3d_bwd(int dtype, const void* dy, int64_t ld_dy, int6
     SEGK_CHECK_VOL("avgpool3d_bwd(dy)", dy, ld_dy, C, dtype);
     SEGK_CHECK_VOL("avgpool3d_bwd(dx)", dx, ld_dx, C, dtype);
     SEGK_REQUIRE(N > 0 && D >= 2 && H >= 2 && W >= 2 && N * D * H * W < (1ll << 31), SEGK_ESHAPE, "avgpool3d_bwd: every extent must be >= 2");
-    SEGK_HIP(use_device(dev));
+    SEGK_USE_DEVICE(dev);
     const int64_t items = N * D * H * W * (C / 8);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((avgpool3d_bwd_kernel<T>), dim3(vgrid(items)), dim3(kVThreads), 0, (hipStream_t)stream,
                                                      (const T*)dy, ld_dy, N, (int)D, (int)H, (int)W, (int)C, (T*)dx, ld_dx, (flags >> 1) & 1));

@@ -751,7 +751,7 @@ class UNetVggWholeImg(nn.Module):
     def __init__(self, save_model_path, out_classes=3):
         super().__init__()
         self.unetvgg = UNetVgg()
-        checkpoint = torch.load(save_model_path)
+        checkpoint = torch.load(save_model_path, map_location='cpu', weights_only=True)
         self.unetvgg.load_state_dict(checkpoint['state_dict'])
 
     def forward(self, x):

@@ -1,5 +1,4 @@
-"""`train_model` / `test_model`: the lightning branch of the reference's `train_general`
-(/root/reference/pl_utils/pl_train.py:6-44, /root/reference/pl_utils/pl_test.py:3-26)."""
+"""`train_model`: the lightning branch of the reference's `train_general` (/root/reference/pl_utils/pl_train.py:6-44)."""
 import os
 import shutil
 
@@ -26,14 +25,4 @@ def train_model(lightn_model, checkpoint_path, del_pre_files=True, device=None, 
     return trainer
 
 
-def test_model(model, checkpoint_path, trainer):
-    """Reload the saved best checkpoint (first file with "epoch" in its name) and run the test loop."""
-    if trainer is None:
-        return None
-    for name in sorted(os.listdir(checkpoint_path)):
-        path = os.path.join(checkpoint_path, name)
-        if os.path.isfile(path) and "epoch" in name:
-            checkpoint = torch.load(path, map_location="cpu", weights_only=True)
-            model.load_state_dict(checkpoint['state_dict'])
-            break
-    return trainer.test(model)
+from .pl_test import test_model  # noqa: E402,F401  (kept importable from here; its home is pl_utils/pl_test.py as in the reference)

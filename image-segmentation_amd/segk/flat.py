@@ -100,9 +100,31 @@ class GradBuckets:
 
 
 class FlatModel:
+    """Flat storage for the trainable parameters of `net`: a SegkNet, or a wrapper module (UNetVgg256, UNetVggTwo,
+    SegmModelPL ...) whose trainable parameters all live inside SegkNet sub-modules.  The tape of every such network
+    gets hooks that translate its own parameter names to the wrapper's (prefixed) names.  Parameters with
+    requires_grad=False stay where they are: they are neither bucketed, all-reduced nor touched by the optimizer."""
+
     def __init__(self, net, bucket_mb=25.0, group=None, broadcast=True):
+        from .net import SegkNet
         self.net = net
-        named = list(net.named_parameters())[::-1]            # backward completion order
+        if isinstance(net, SegkNet):
+            targets = [("", net)]
+        else:
+            targets, seen = [], []
+            for mname, m in net.named_modules():
+                if isinstance(m, SegkNet) and not any(mname.startswith(s + ".") for s in seen):
+                    seen.append(mname)
+                    targets.append((mname + ".", m))
+            if not targets:
+                raise TypeError(f"FlatModel needs a SegkNet or a module that contains one, got {type(net).__name__}")
+            outside = [n for n, p in net.named_parameters()
+                       if p.requires_grad and not any(n.startswith(pre) for pre, _ in targets)]
+            if outside:
+                raise TypeError(f"FlatModel: trainable parameters outside the tape networks are not supported: {outside[:4]}")
+        named = [(n, p) for n, p in list(net.named_parameters())[::-1] if p.requires_grad]   # backward completion order
+        if not named:
+            raise ValueError("FlatModel: the module has no trainable parameter")
         device = named[0][1].device
         sizes = [(n, p.numel()) for n, p in named]
         self.buckets = GradBuckets(sizes, int(bucket_mb * (1 << 20)), group=group, device=device)
@@ -120,9 +142,10 @@ class FlatModel:
         if broadcast and self.buckets.world > 1:
             import torch.distributed as dist
             dist.broadcast(self.flat_param, src=0, group=group)
-            # BatchNorm buffers: one coalesced broadcast per dtype instead of one per tensor
+            # frozen parameters and BatchNorm buffers: one coalesced broadcast per dtype instead of one per tensor
+            frozen = [p for p in net.parameters() if not p.requires_grad]
             for dtype in (torch.float32, torch.int64):
-                bufs = [b for b in net.buffers() if b.dtype == dtype]
+                bufs = [b for b in list(net.buffers()) + frozen if b.dtype == dtype]
                 if not bufs:
                     continue
                 flat = torch.cat([b.detach().reshape(-1) for b in bufs])
@@ -131,17 +154,41 @@ class FlatModel:
                 for b in bufs:
                     b.data.copy_(flat[off:off + b.numel()].view_as(b))
                     off += b.numel()
-        net._segk_grad_hooks = (self._sink, self._alloc, self._begin, self._finish)
+        # several tape networks under one wrapper (each run once per step) do their backward passes one after the other
+        # within ONE autograd backward: the bucket state is reset when the first starts and checked when the last is done
+        self._done = 0
+        self._ntargets = len(targets)
+        for prefix, m in targets:
+            m._segk_grad_hooks = (self._make_sink(prefix), self._make_alloc(prefix), self._begin, self._finish)
 
     # hooks called by the tape
     def _begin(self):
-        self.buckets.reset()
+        if self._done == 0:
+            self.buckets.reset()
 
+    def _make_alloc(self, prefix):
+        def alloc(name, like):
+            view = self.views.get(prefix + name)
+            if view is None:                      # frozen parameter: the tape's gradient goes to a throw-away tensor
+                return torch.empty_like(like, dtype=torch.float32)
+            return view
+        return alloc
+
+    def _make_sink(self, prefix):
+        def sink(name, tensor):
+            if prefix + name in self.views:
+                self.buckets.mark(prefix + name, self.flat_grad)
+        return sink
+
+    # single-network spellings kept for callers that drive the hooks by hand
     def _alloc(self, name, like):
-        return self.views[name]
+        return self._make_alloc("")(name, like)
 
     def _sink(self, name, tensor):
-        self.buckets.mark(name, self.flat_grad)
+        self._make_sink("")(name, tensor)
 
     def _finish(self):
-        self.buckets.finish()
+        self._done += 1
+        if self._done >= self._ntargets:
+            self._done = 0
+            self.buckets.finish()

@@ -1,5 +1,7 @@
 """Fused softmax + squared-Dice + focal loss on the GPU (autograd.Function over the C ABI) and the
 arg-max Dice metric.  CPU tensors are served by the same formulas in torch ops (`_host_*`)."""
+import weakref
+
 import torch
 import torch.nn.functional as F
 
@@ -45,6 +47,7 @@ class _DiceFocalFn(torch.autograd.Function):
         call("segk_dice_focal_finalize", sums.data_ptr(), iflags.data_ptr(), N, C, HW, flags, scalars.data_ptr(), dev, st)
         ctx.save_for_backward(z, labels if labels is not None else hot, sums, iflags, scalars)
         ctx.meta = (N, C, HW, float(gamma), al, flags, labels is not None, logits.dtype)
+        ctx.token = _SHARED.get("pending")      # set by dice_focal(): marks the shared node as spent once it has run backward
         ctx.set_materialize_grads(False)
         outs = (scalars[0], scalars[1])
         if want_map:
@@ -56,6 +59,8 @@ class _DiceFocalFn(torch.autograd.Function):
     def backward(ctx, g_dice, g_focal, *unused):
         z, tgt, sums, iflags, scalars = ctx.saved_tensors
         N, C, HW, gamma, al, flags, is_labels, in_dtype = ctx.meta
+        if ctx.token is not None:
+            ctx.token["spent"] = True
         gs = torch.zeros(2, dtype=torch.float32, device=z.device)
         if g_dice is not None:
             gs[0] = -g_dice.float()          # the kernel differentiates the loss 1 - coefficient
@@ -75,11 +80,44 @@ def _as_square_labels(act):
     return act.view(act.shape[0], 1, act.shape[2], act.shape[2])
 
 
+# The training loops add the two losses of ONE (logits, target) pair: `dice_loss_sq(out, t) + focal_loss_with_logits(out, t)`
+# (perlosstrain/naive_train.py:421-423, pl_utils/pl_mod.py:64-67).  The fused kernels compute both, so the second call
+# re-uses the autograd node of the first: one forward launch, and one backward launch that receives both upstream
+# gradients and writes dlogits once.  The entry is valid while both tensors are alive and unmodified, the focal
+# parameters agree, and the node has not run its backward yet.
+_SHARED = {}
+
+
+def _shared_lookup(pred, target, gamma, alpha, flags, grad):
+    e = _SHARED.get("entry")
+    if e is None or e["token"]["spent"]:
+        return None
+    if e["pred"]() is not pred or e["target"]() is not target or e["versions"] != (pred._version, target._version):
+        return None
+    if e["key"] != (float(gamma), None if alpha is None else id(alpha), flags, grad):
+        return None
+    return e["outs"]
+
+
 def dice_focal(pred, target, gamma=2.0, alpha=None, no_sft=False, is_all_chann=False, focal_sum=False, want_map=False,
                self_adjusting=False):
     flags = (NO_SFT if no_sft else 0) | (ALL_CHANN if is_all_chann else 0) | (FOCAL_SUM if focal_sum else 0) | \
         (SELF_ADJ if self_adjusting else 0)
-    return _DiceFocalFn.apply(pred, target, gamma, alpha, flags, want_map)
+    if want_map:
+        return _DiceFocalFn.apply(pred, target, gamma, alpha, flags, True)
+    grad = torch.is_grad_enabled() and pred.requires_grad
+    outs = _shared_lookup(pred, target, gamma, alpha, flags, grad)
+    if outs is not None:
+        return outs
+    token = {"spent": False}
+    _SHARED["pending"] = token
+    try:
+        outs = _DiceFocalFn.apply(pred, target, gamma, alpha, flags, False)
+    finally:
+        _SHARED["pending"] = None
+    _SHARED["entry"] = {"pred": weakref.ref(pred), "target": weakref.ref(target), "versions": (pred._version, target._version),
+                        "key": (float(gamma), None if alpha is None else id(alpha), flags, grad), "token": token, "outs": outs}
+    return outs
 
 
 # ------------------------------------------------------------------------------------ public: Dice
@@ -216,6 +254,10 @@ def focal_loss_with_logits(p, t, gamma=2., alpha=None, reduction='elementwise_me
     if reduction not in ('elementwise_mean', 'none', 'sum'):
         raise ValueError('Reduction parameter unknown.')
     if reduction == 'none':
+        if torch.is_grad_enabled() and p.requires_grad:
+            # the per-pixel map with a gradient: element-wise torch ops (differentiable like the reference's map,
+            # loss/focal.py:64-75); the fused kernels serve the reduced losses of the training loops and the map without grad
+            return _host_focal(p, t, gamma, alpha, reduction)
         out = dice_focal(p, t, gamma=gamma, alpha=alpha, want_map=True)
         return out[2].to(p.dtype)
     _, loss = dice_focal(p, t, gamma=gamma, alpha=alpha, focal_sum=(reduction == 'sum'))

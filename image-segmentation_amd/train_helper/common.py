@@ -37,7 +37,8 @@ def train_general(dataset, out_path, expt_name="", val_set_perc=0.15, test_set_p
         val_acc_func = dice_coefficient
     if not is_naive_train:
         from pl_utils.pl_mod import SegmModelPL
-        from pl_utils.pl_train import test_model, train_model
+        from pl_utils.pl_test import test_model
+        from pl_utils.pl_train import train_model
         lightn_mod = SegmModelPL(net_model, train_set, val_set, test_set, batch_size, test_batch_size, loss_criterion=loss_criterion,
                                  val_acc_func=val_acc_func, lr=lr, experiment_name=expt_name).to(device)
         trainer = train_model(lightn_mod, out_path, del_pre_files=True, device=device, num_epochs=num_epochs)

@@ -88,3 +88,93 @@ def test_bucket_partition_covers_flat_buffer():
     assert b.bucket_of["a"] == b.bucket_of["b"] == 0 and b.bucket_of["c"] == 1 and b.bucket_of["e"] == 2
     with pytest.raises(AssertionError):
         b.finish()                                     # nothing was marked: incomplete buckets are an error
+
+
+def _wrapper_worker(rank, world, port, q):
+    """A wrapper module around two tape networks (the shape of UNetVggTwo / SegmModelPL) plus a frozen parameter."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "image-segmentation_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from models.unetplusplus import conv_block_nested
+    from segk.flat import FlatModel
+
+    class Two(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.left = conv_block_nested(8, 8, 8)
+            self.right = conv_block_nested(8, 8, 8)
+
+    torch.manual_seed(7 + rank)
+    net = Two()
+    net.right.bn2.bias.requires_grad_(False)            # frozen: neither bucketed nor all-reduced
+    flat = FlatModel(net, bucket_mb=0.0005)
+    assert "right.bn2.bias" not in flat.views and "left.conv1.weight" in flat.views
+    assert net.left._segk_grad_hooks is not None and net.right._segk_grad_hooks is not None
+    expect = {}
+    # autograd runs the two tapes' backward passes one after the other: right first (it was used last), then left
+    for sub_name in ("right", "left"):
+        sub = getattr(net, sub_name)
+        sink, alloc, begin, finish = sub._segk_grad_hooks
+        begin()
+        g = torch.Generator().manual_seed(31 * rank + len(sub_name))
+        for n, p in reversed(list(sub.named_parameters())):
+            buf = alloc(n, p)
+            val = torch.randn(p.shape, generator=g)
+            buf.copy_(val)
+            if p.requires_grad:
+                assert buf.data_ptr() == p.grad.data_ptr()
+                expect[sub_name + "." + n] = val
+            else:
+                assert p.grad is None
+            sink(n, buf)
+        finish()                                         # only the last network's finish waits for the buckets
+    assert sorted(flat.buckets.launched) == list(range(len(flat.buckets.ranges)))
+    for n, val in expect.items():
+        both = [torch.zeros_like(val) for _ in range(world)]
+        dist.all_gather(both, val)
+        assert torch.allclose(dict(net.named_parameters())[n].grad, sum(both) / world, rtol=1e-6, atol=1e-7), n
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_flat_model_over_a_wrapper_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wrapper_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+def test_flat_model_rejects_modules_without_a_tape_network():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "image-segmentation_amd"))
+    from segk.flat import FlatModel
+    with pytest.raises(TypeError, match="SegkNet"):
+        FlatModel(torch.nn.Linear(4, 4))
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher around it must run two ranks (rendezvous-only dry run on the CPU),
+    and a rank count that contradicts --gpus must be an error, not a silently mislabelled one-rank run."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 3
+    env["WORLD_SIZE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                       text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr

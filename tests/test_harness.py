@@ -154,3 +154,10 @@ def test_mid_slice_training_gpu(tmp_path):
         a = cpu_model.eval()(x[None])
         b = out.eval()(x[None].cuda()).cpu()
     assert float((a - b).norm() / a.norm()) < 1e-3
+
+
+def test_pl_test_module_path_matches_the_reference():
+    """detect_region/common.py:13 of the reference does `from pl_utils.pl_test import test_model`."""
+    from pl_utils.pl_test import test_model
+    from pl_utils.pl_train import test_model as same
+    assert test_model is same and test_model(None, "/nonexistent", None) is None
