@@ -15,6 +15,7 @@
 // four accumulator registers are four CONSECUTIVE output channels of one pixel -> one 8/16-byte store.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace segk {
 
@@ -130,9 +131,17 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 // the MFMAs.  3 or 4 (thin layers, one or two K-rows: memory-latency bound, few steps per tile): ONE halo buffer and no
 // halo prefetch, 33-49 KB of LDS and <= 128/170 registers, so that three or four workgroups share a CU and their
 // load phases overlap each other's MFMAs.
-template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES, int WGS = 2>
+//
+// PIPE (every K-row full, i.e. two k-substeps each; two halo buffers): the loop is skewed by half a step.  The barrier
+// that publishes the weights of step s+1 sits between the two k-substeps' MFMA groups: behind it come the MFMAs of
+// (s, substep 1), whose fragments are already in registers, so the LDS latency of the first reads from the freshly
+// published weight buffer hides under 16 MFMAs instead of being paid after every barrier; the fragments of substep 1
+// are read while substep 0 is multiplied.  All loop conditions except "first step of the tile" are compile-time
+// (the last K-row is peeled), so a K-row is one straight-line block of 9 taps.
+template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES, int WGS = 2, bool PIPE = false>
 __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_WAVES * WCO_WAVES)) void conv_fwd_kernel(const ConvArgs a) {
     constexpr bool ONE_HALO = WGS > 2;
+    static_assert(!PIPE || (!ONE_HALO && sizeof(T) == 2), "the skewed loop is built for bf16 with two halo buffers");
     constexpr int NT = 64 * WPX_WAVES * WCO_WAVES;   // threads: 4 waves (two workgroups per CU) or 8 waves (one)
     constexpr int PAD = TAPS == 1 ? 0 : 1;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_;
@@ -260,6 +269,75 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 #pragma unroll
         for (int c = 0; c < 8; ++c) boff[ks][c] = hp_l * kRowBytes + (((ks * 4 + g) ^ ((hp_l + c) & 7)) << 4);
 
+    if constexpr (PIPE) {
+        Slot fa0[NI], fb0[NJ], fa1[NI], fb1[NJ];
+        auto mma_all = [&](const Slot (&fa)[NI], const Slot (&fb)[NJ]) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) Mma<T>::run(fa[i], fb[j], acc[i][j]);
+        };
+        // one K-row: NEXT = another K-row follows (its halo streams in behind taps 0 .. HPARTS-1)
+        auto krow = [&](int chunk, auto next_tag) {
+            constexpr bool NEXT = decltype(next_tag)::value;
+            const char* hb = s_halo0 + (chunk & 1) * HBYTES;
+            auto read_b = [&](int tap, int ks, Slot (&fb)[NJ]) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    if constexpr (TAPS != 4) {
+                        const int ky = TAPS == 9 ? tap / 3 : 0, kx = TAPS == 9 ? tap % 3 : 0;
+                        const int c = (j + ky) * HW_ + kx;
+                        fb[j] = *reinterpret_cast<const Slot*>(hb + boff[ks][c & 7] + c * kRowBytes);
+                    } else {
+                        const int hp = hp_l + (j + a.tky[tap]) * HW_ + a.tkx[tap];
+                        fb[j] = *reinterpret_cast<const Slot*>(hb + hp * kRowBytes + (((ks * 4 + g) ^ (hp & 7)) << 4));
+                    }
+                }
+            };
+            auto read_a = [&](const char* wb, int ks, Slot (&fa)[NI]) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int co = co_l + i * 16;
+                    fa[i] = *reinterpret_cast<const Slot*>(wb + co * kRowBytes + (((ks * 4 + g) ^ (co & 7)) << 4));
+                }
+            };
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int step = chunk * TAPS + tap;
+                const char* wb = s_w0 + (step & 1) * WBYTES;
+                constexpr bool kMoreW = true;
+                const bool more_w = NEXT || tap + 1 < TAPS;
+                const bool halo_now = NEXT && tap < HPARTS;
+                // behind the barrier: DMA for the next step (its buffer was last read one step ago), this step's
+                // substep-0 fragments from the buffer that barrier published
+                if (more_w) stage_w(step + 1, (step + 1) & 1);
+                if (halo_now) stage_halo_part(chunk + 1, (chunk + 1) & 1, tap);
+                read_a(wb, 0, fa0);
+                read_b(tap, 0, fb0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap > 0 || chunk > 0) mma_all(fa1, fb1);          // (previous step, substep 1)
+                __builtin_amdgcn_sched_barrier(0);
+                read_a(wb, 1, fa1);
+                read_b(tap, 1, fb1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_all(fa0, fb0);                                     // (this step, substep 0)
+                __builtin_amdgcn_sched_barrier(0);
+                // every read of this step's weight buffer has returned (the next step's DMA overwrites it), the next
+                // step's weights have landed; the halo parts issued in this step may stay in flight, except behind the
+                // K-row's last tap, where the next K-row's halo is about to be read
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (tap == TAPS - 1 || !halo_now) dma_wait_all();
+                else dma_wait_but<HL>();
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                (void)kMoreW;
+            }
+        };
+        for (int chunk = 0; chunk + 1 < a.nch; ++chunk) krow(chunk, std::true_type{});
+        krow(a.nch - 1, std::false_type{});
+        mma_all(fa1, fb1);                                             // (last step, substep 1)
+    } else
     for (int chunk = 0; chunk < a.nch; ++chunk) {
         // a K-row whose second half holds no real channels (C = 32 in bf16, the 27-value patch row of the first
         // convolution, the tail of a 96-channel concat) is multiplied with one k-substep instead of two
@@ -934,6 +1012,14 @@ static void launch_fwd_t(const ConvArgs& a, int bn, hipStream_t st) {
             if (bn == 96) hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 96, 4, 1, 3>), dim3(grid), dim3(kConvThreads), 0, st, a);
             else if (bn == 64) hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 64, 2, 2, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
             else hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 32, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
+            return;
+        }
+    }
+    if constexpr (sizeof(T) == 2 && TAPS == 9) {
+        static const bool no_pipe = getenv("SEGK_NO_PIPE") != nullptr;
+        const bool full_rows = a.C0 % 64 == 0 && a.C1 % 64 == 0;
+        if (bn == 128 && full_rows && !no_pipe) {
+            hipLaunchKernelGGL((conv_fwd_kernel<T, TAPS, 8, 128, 2, 2, 2, true>), dim3(grid), dim3(kConvThreads), 0, st, a);
             return;
         }
     }

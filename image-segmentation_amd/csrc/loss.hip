@@ -2,6 +2,7 @@
 // arg-max Dice metric.  HBM-bound streams: every logit is read once per pass, reductions go
 // wavefront shuffle -> LDS -> per-block partial -> fixed-order finalize (deterministic).
 #include "common.h"
+#include <mutex>
 
 namespace segk {
 
@@ -434,6 +435,62 @@ extern "C" int segk_dice_focal_fwd(const void* logits, int logits_dtype, const i
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(dice_focal_collect_kernel, dim3((unsigned)N), dim3(64), 0, st, (const float*)workspace, bpi, (int)C,
                        out_sums, out_flags);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// ----------------------------------------------------------------------------------------------
+// The same forward for callers that cannot allocate (HIP graph capture, tight serving loops): the block partials go to
+// a fixed device array of this code object instead of a caller-provided workspace.  `scratch` is only a host-side
+// stand-in for the symbol; the device address is looked up once per device with hipGetSymbolAddress and that pointer
+// is what the kernels receive.  Every GPU holds its own copy of the array until the process ends.
+// ----------------------------------------------------------------------------------------------
+namespace segk {
+constexpr size_t kStaticScratchBytes = 1u << 20;     // 1 MiB: e.g. 2978 images x 4 classes at 384 x 384
+constexpr int kMaxDevices = 64;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static void* g_scratch_ptr[kMaxDevices] = {};
+static std::mutex g_scratch_mutex;
+
+// device address of `scratch` on device `dev`, which must be the calling thread's current device
+static int static_scratch(int dev, void** out) {
+    SEGK_REQUIRE(dev >= 0 && dev < kMaxDevices, SEGK_EINVAL, "static scratch: device index %d out of range", dev);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        SEGK_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        SEGK_REQUIRE(ptr != nullptr, SEGK_EHIP, "static scratch: hipGetSymbolAddress returned a null pointer");
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return SEGK_OK;
+}
+}  // namespace segk
+
+extern "C" int segk_dice_focal_fwd_static(const void* logits, int logits_dtype, const int64_t* labels, const float* hot,
+                                          int64_t N, int64_t C, int64_t HW, float gamma, const float* alpha, int flags,
+                                          float* out_sums, int32_t* out_flags, float* focal_map, int dev, void* stream) {
+    SEGK_REQUIRE(logits && out_sums && out_flags, SEGK_EINVAL, "dice_focal_fwd_static: null pointer");
+    SEGK_REQUIRE((labels != nullptr) != (hot != nullptr), SEGK_EINVAL, "dice_focal_fwd_static: exactly one of labels/hot");
+    SEGK_REQUIRE(N > 0 && HW > 0 && N < 65536 && C >= 1 && C <= kMaxC, SEGK_ESHAPE, "dice_focal_fwd_static: bad N=%lld C=%lld HW=%lld",
+                 (long long)N, (long long)C, (long long)HW);
+    const size_t need = segk_dice_focal_workspace(N, C, HW);
+    SEGK_REQUIRE(need <= kStaticScratchBytes, SEGK_EWORKSPACE,
+                 "dice_focal_fwd_static: this shape needs %zu bytes of block partials, the static scratch holds %zu; use "
+                 "segk_dice_focal_fwd with a workspace", need, kStaticScratchBytes);
+    SEGK_REQUIRE(!focal_map || labels, SEGK_EINVAL, "dice_focal_fwd_static: focal map needs integer labels");
+    SEGK_USE_DEVICE(dev);
+    void* ws = nullptr;
+    if (int rc = static_scratch(dev, &ws)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int bpi = loss_bpi(N, HW);
+    // every block writes all of its 4*C+1 partial slots and the collect kernel reads exactly the slots of this launch,
+    // so nothing in the scratch has to start at zero and a previous call's (larger) contents are never read
+    SEGK_DISPATCH_C(C, SEGK_DISPATCH_DTYPE(logits_dtype, TL, (launch_fwd<TL, CC>(logits, labels, hot, N, HW, gamma, alpha, flags,
+                                                                                  focal_map, (float*)ws, bpi, st))));
+    SEGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(dice_focal_collect_kernel, dim3((unsigned)N), dim3(64), 0, st, (const float*)ws, bpi, (int)C, out_sums,
+                       out_flags);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -22,6 +22,7 @@ _PROTOS = {
     "segk_version": (I, []),
     "segk_dice_focal_workspace": (Z, [L, L, L]),
     "segk_dice_focal_fwd": (I, [P, I, P, P, L, L, L, F, P, I, P, P, P, P, Z, I, P]),
+    "segk_dice_focal_fwd_static": (I, [P, I, P, P, L, L, L, F, P, I, P, P, P, I, P]),
     "segk_dice_focal_finalize": (I, [P, P, L, L, L, I, P, I, P]),
     "segk_dice_focal_bwd": (I, [P, I, P, P, L, L, L, F, P, I, P, P, P, P, P, I, P]),
     "segk_argmax_dice": (I, [P, I, P, L, L, L, P, P, P, I, P]),

@@ -63,6 +63,18 @@ int segk_dice_focal_fwd(const void* logits, int logits_dtype, const int64_t* lab
                         float* out_sums, int32_t* out_flags, float* focal_map, void* workspace,
                         size_t workspace_bytes, int dev, void* stream);
 
+/* segk_dice_focal_fwd for callers that cannot allocate device memory (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc): identical arguments and results, but the block partials go to a fixed
+ * 1 MiB device array inside the library instead of a caller-provided workspace, and the call makes no hipMalloc /
+ * hipFree (nor any other allocating call).  No counterpart in the reference.
+ * Limit: segk_dice_focal_workspace(N, C, HW) <= 1048576 bytes (e.g. up to 2978 images of 4 classes at 384 x 384),
+ * larger shapes return SEGK_EWORKSPACE.  Every GPU the library runs on holds its own copy of the array until the
+ * process ends; all calls on one GPU share it, so calls that overlap on one GPU (different streams or threads) race --
+ * serialise them, or use segk_dice_focal_fwd.  Nothing in the array has to be cleared between calls.          */
+int segk_dice_focal_fwd_static(const void* logits, int logits_dtype, const int64_t* labels, const float* hot,
+                               int64_t N, int64_t C, int64_t HW, float gamma, const float* alpha, int flags,
+                               float* out_sums, int32_t* out_flags, float* focal_map, int dev, void* stream);
+
 /* Reduce the per-(n,c) sums to the two scalars the reference returns.
  * replaces: loss/dice.py:72-87 (dice table, bg drop, fg-image average; loss = 1 - coeff at :23) and
  *           loss/focal.py:24-29 (mean over N*C*H*W or sum).
