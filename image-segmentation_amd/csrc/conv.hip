@@ -16,6 +16,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace segk {
 
@@ -95,6 +96,23 @@ template <> struct Mma<float> {
         c = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(float, a.w), __builtin_bit_cast(float, b.w), c, 0, 0, 0);
     }
 };
+
+#ifdef SEGK_CLOCK_PROBE
+// Diagnostic build only (make probe): shader-clock and 100 MHz real-time stamps around the main loop of the first
+// workgroups, written to a buffer nothing else reads; the ratio is the clock the chip holds inside the kernel.
+__device__ unsigned long long g_clock_probe[1024][4];
+#define SEGK_PROBE_BEGIN()                                                                              \
+    unsigned long long probe_t0 = 0, probe_r0 = 0;                                                      \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) { probe_t0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
+#define SEGK_PROBE_END()                                                                                \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                        \
+        g_clock_probe[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - probe_t0;                         \
+        g_clock_probe[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - probe_r0;                     \
+    }
+#else
+#define SEGK_PROBE_BEGIN()
+#define SEGK_PROBE_END()
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
@@ -269,6 +287,7 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 #pragma unroll
         for (int c = 0; c < 8; ++c) boff[ks][c] = hp_l * kRowBytes + (((ks * 4 + g) ^ ((hp_l + c) & 7)) << 4);
 
+    SEGK_PROBE_BEGIN();
     if constexpr (PIPE) {
         Slot fa0[NI], fb0[NJ], fa1[NI], fb1[NJ];
         auto mma_all = [&](const Slot (&fa)[NI], const Slot (&fb)[NJ]) {
@@ -422,6 +441,7 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
         }
     }
 
+    SEGK_PROBE_END();
     // ---- epilogue: bias, ReLU, mask, store 8 consecutive channels per lane (rows are in MFMA order) ----------
     static_assert(NI % 2 == 0, "channel tiles come in pairs");
     if (!a.stat_part) {
@@ -662,7 +682,7 @@ template <> __device__ __forceinline__ int wg_swz<float>(int pix) { return (pix 
 // GI x GJ = 4: wave grid.  <4,4,2,2> is the square 64x64 block (bf16); <2,4,1,4> serves dy with <= 32 channels,
 // <4,2,4,1> an input K-row with <= 32 channels, without multiplying the zero half.
 template <typename T, int TAPS, int TDI, int TDJ, int GI, int GJ>
-__global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(kConvThreads, 2) void conv_wgrad_kernel(const WgradArgs a) {
     constexpr int TH = 8;
     constexpr int PAD = TAPS == 1 ? 0 : 1;
     constexpr int HH = TH + 2 * PAD, HW_ = kTW + 2 * PAD, HPIX = HH * HW_, TPIX = TH * kTW;
@@ -789,6 +809,99 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
     dma_wait_all();
     __syncthreads();
 
+    if constexpr (kBf16 && TAPS == 9) {
+        // 3x3, bf16: a software pipeline over "groups".  Group (K-step kk, kx, j) = the three ky fragments of input-channel
+        // tile j at column shift kx (six transposing row reads) and their 3 x WTI MFMAs.  The reads of group g+DEPTH are
+        // issued in front of the MFMAs of group g, so every fragment has DEPTH groups of MFMAs to arrive.  A halo row that two ky
+        // taps share (as the high half of one fragment and the low half of the next) is read twice, once into each
+        // fragment's registers: the LDS has the bandwidth, and the matrix pipe is spared two register moves per MFMA.
+        // The pipeline runs across tiles: the barrier that ends a tile sits in front of its last DEPTH groups' MFMAs, whose
+        // fragments are in registers by then, and the first DEPTH groups of the next tile are read right behind it.
+        typedef __attribute__((address_space(3))) char* lds_cptr;
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        constexpr int STAGE = XBYTES + DBYTES;
+        constexpr int KSTEPS = TPIX / 32, GPK = 3 * WTJ, NG = KSTEPS * GPK;
+        // prefetch distance in groups: 2 where the registers allow it, 1 for the square 64 x 64 block (144 accumulators)
+        constexpr int DEPTH = WTI * WTJ >= 4 ? 1 : 2, NS = DEPTH + 1;
+        static_assert(NG % NS == 0 && NG > DEPTH, "the fragment slots rotate with period NS");
+        auto rd = [&](unsigned adr, int off) {
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)((lds_cptr)(size_t)adr + off));
+        };
+        auto join = [](const s16x4& lo, const s16x4& hi) {
+            s16x8 f;
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            return f;
+        };
+        s16x8 fb[NS][3];       // [slot = group % NS][ky]
+        s16x8 fa[2][WTI];      // [K-step parity][output-channel tile]
+        // reads of group gi of the tile staged at LDS offset stoff; the group that opens a K-step also brings that
+        // K-step's output-gradient fragments
+        auto read_group = [&](auto gtag, unsigned stoff) {
+            constexpr int gi = decltype(gtag)::value;
+            constexpr int kk = gi / GPK, kx = (gi % GPK) / WTJ, j = gi % WTJ, slot = gi % NS;
+            const unsigned b = adrB[kx][j] + stoff;
+            s16x4 lo[3], hi[3];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) lo[ky] = rd(b, (2 * kk + ky) * HW_ * kRowBytes);
+            asm volatile("" ::: "memory");        // the second read of a shared row is a read of its own, not a copy
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) hi[ky] = rd(b, (2 * kk + ky + 1) * HW_ * kRowBytes);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) fb[slot][ky] = join(lo[ky], hi[ky]);
+            if constexpr (gi % GPK == 0) {
+#pragma unroll
+                for (int i = 0; i < WTI; ++i) {
+                    const unsigned aa = adrA[i] + stoff;
+                    fa[kk & 1][i] = join(rd(aa, 2 * kk * kTW * kRowBytes), rd(aa, (2 * kk + 1) * kTW * kRowBytes));
+                }
+            }
+            asm volatile("" ::: "memory");
+        };
+        auto mma_group = [&](auto gtag) {
+            constexpr int gi = decltype(gtag)::value;
+            constexpr int kk = gi / GPK, kx = (gi % GPK) / WTJ, j = gi % WTJ, slot = gi % NS;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int i = 0; i < WTI; ++i)
+                    acc[ky * 3 + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, fb[slot][ky]), __builtin_bit_cast(bf16x8, fa[kk & 1][i]), acc[ky * 3 + kx][i][j], 0, 0, 0);
+        };
+        auto for_groups = [&](auto&& body) {
+            [&]<int... G>(std::integer_sequence<int, G...>) { (body(std::integral_constant<int, G>{}), ...); }(
+                std::make_integer_sequence<int, NG>{});
+        };
+        if (t_lo < t_hi) {
+            if (t_lo + 1 < t_hi) stage(t_lo + 1, 1);
+            read_group(std::integral_constant<int, 0>{}, 0u);
+            if constexpr (DEPTH == 2) read_group(std::integral_constant<int, 1>{}, 0u);
+        }
+        unsigned stoff = 0;
+        for (int tile = t_lo; tile < t_hi; ++tile, stoff = STAGE - stoff) {
+            const bool has_next = tile + 1 < t_hi;
+            for_groups([&](auto gtag) {
+                constexpr int gi = decltype(gtag)::value;
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (gi + DEPTH < NG) {
+                    read_group(std::integral_constant<int, gi + DEPTH>{}, stoff);
+                } else if constexpr (gi == NG - DEPTH) {
+                    if (has_next) {
+                        // every fragment of this tile is in registers; the next tile has landed in the other stage
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        dma_wait_all();
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (tile + 2 < t_hi) stage(tile + 2, stoff ? 1 : 0);      // into the stage just released
+                        read_group(std::integral_constant<int, 0>{}, STAGE - stoff);
+                        if constexpr (DEPTH == 2) read_group(std::integral_constant<int, 1>{}, STAGE - stoff);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group(gtag);
+            });
+        }
+    } else {
     int st = 0;
     for (int tile = t_lo; tile < t_hi; ++tile, st ^= 1) {
         // next tile's DMA goes out first and lands in the other stage while this tile is multiplied
@@ -911,6 +1024,7 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_kernel(const WgradArg
         __builtin_amdgcn_sched_barrier(0);
         dma_wait_all();
         __syncthreads();
+    }
     }
 
     // partial slab: slab[split][co][tap][ci].  The input-channel tile is the MFMA's row operand, so a lane holds four
@@ -1615,3 +1729,12 @@ extern "C" int segk_convd_wgrad(int dtype, const void* x, int64_t ldx, int64_t C
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
+
+#ifdef SEGK_CLOCK_PROBE
+// diagnostic build only: copy the stamps of the last convolution launch to the host ([1024][4] x 8 bytes)
+extern "C" int segk_debug_clock_probe(unsigned long long* out_host) {
+    SEGK_HIP(hipDeviceSynchronize());
+    SEGK_HIP(hipMemcpyFromSymbol(out_host, HIP_SYMBOL(segk::g_clock_probe), sizeof(unsigned long long) * 1024 * 4));
+    return SEGK_OK;
+}
+#endif
