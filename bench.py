@@ -175,6 +175,8 @@ def main():
     ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid", "unetsimple", "spidernet"])
     ap.add_argument("--depth", type=int, default=64, help="slices per volume (detectmid)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL)")
+    ap.add_argument("--deep-sup", action="store_true",
+                    help="unetpp only: four supervised heads on x(0,1)..x(0,4), loss = sum over heads of Dice + focal (BASELINE configs[3])")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --batch is the GLOBAL batch, split over the ranks")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher self-test: rendezvous of the N ranks on the CPU (gloo), no GPU work, prints the rank count")
@@ -224,6 +226,7 @@ def main():
 
     from loss.dice import dice_loss_sq
     from loss.focal import focal_loss_with_logits
+    from models.unetplusplus import deep_supervision_loss
     from models.unetvgg import UNetVgg
     from segk import ops
     from segk.flat import FlatModel
@@ -242,8 +245,8 @@ def main():
         gflop = detectmid_gflop(model, args.depth, args.side)
     elif args.model == "unetpp":
         from models.unetplusplus import Nested_UNet
-        model = Nested_UNet(in_ch=1, out_ch=n_classes)
-        gflop = 1859.61
+        model = Nested_UNet(in_ch=1, out_ch=n_classes, deep_supervision=args.deep_sup)
+        gflop = 1859.61                            # 3x3 convolutions; the 1x1 heads run as streaming kernels
     elif args.model == "unetsimple":
         # the configuration the reference trains (roi_train/train_roi.py:39): one input channel, channelscale 128
         from models.unetvgg import UNetSimple
@@ -274,6 +277,8 @@ def main():
         logits = model(x)
         if args.model == "detectmid":
             loss = torch.nn.functional.cross_entropy(logits, t)      # train_midlslice.py:29
+        elif isinstance(logits, list):                                # deep supervision: summed over the heads
+            loss = deep_supervision_loss(logits, t, [dice_loss_sq, focal_loss_with_logits])
         else:
             loss = dice_loss_sq(logits, t) + focal_loss_with_logits(logits, t)
         loss.backward()
@@ -319,6 +324,8 @@ def main():
         lg = model(x)
         if args.model == "detectmid":
             l2 = torch.nn.functional.cross_entropy(lg, t)
+        elif isinstance(lg, list):
+            l2 = deep_supervision_loss(lg, t, [dice_loss_sq, focal_loss_with_logits])
         else:
             l2 = dice_loss_sq(lg, t) + focal_loss_with_logits(lg, t)
         l2.backward()
@@ -346,14 +353,15 @@ def main():
         out = {
             "metric": ("train volumes/sec (fwd+bwd+loss) DenseNet3D-169 DetectMid " + f"{args.depth}x{args.side}x{args.side}") if args.model == "detectmid" else
                       "train slices/sec (fwd+bwd+loss) " + {"unetvgg": "UNet-VGG", "unetvgg_convtrans": "UNet-VGG (transposed-conv decoder)",
-                                                              "unetpp": "UNet++", "unetsimple": "UNetSimple (channelscale 128)",
+                                                              "unetpp": "UNet++ deep-supervision (4 heads)" if args.deep_sup else "UNet++", "unetsimple": "UNetSimple (channelscale 128)",
                                                               "spidernet": "SpiderNet (channelscale 128)"}[args.model] + f" {args.side}x{args.side}",
             "value": round(value, 2), "unit": "volumes/s" if args.model == "detectmid" else "slices/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"detectmid {args.depth}x{args.side}x{args.side}, 80 classes, {args.batch} volumes/GPU, fwd + cross entropy + bwd + "
                                     if args.model == "detectmid" else
-                                    f"{args.model} {args.side}x{args.side}, {n_classes} classes, {args.batch} slices/GPU, fwd + fused Dice/focal loss + bwd + ")
+                                    f"{args.model}{' deep supervision: 4 heads on x(0,1)..x(0,4), summed Dice/focal' if args.deep_sup else ''} {args.side}x{args.side}, "
+                                    f"{n_classes} classes, {args.batch} slices/GPU, fwd + fused Dice/focal loss + bwd + ")
                                    + f"{'bucketed RCCL all-reduce + ' if world > 1 else ''}fused Adam",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "random_init_weights": True,
                        "final_loss": round(final_loss, 5), "h2d_ms_per_batch": round(h2d_ms, 3),

@@ -19,39 +19,43 @@ from segk.net import SegkNet
 from segk.ops import Act
 
 
-class _DenseLayer(nn.Sequential):
-    def __init__(self, num_input_features, growth_rate, bn_size, drop_rate):
-        super().__init__()
-        self.add_module('norm1', nn.BatchNorm3d(num_input_features))
-        self.add_module('relu1', nn.ReLU(inplace=True))
-        self.add_module('conv1', nn.Conv3d(num_input_features, bn_size * growth_rate, kernel_size=1, stride=1, bias=False))
-        self.add_module('norm2', nn.BatchNorm3d(bn_size * growth_rate))
-        self.add_module('relu2', nn.ReLU(inplace=True))
-        self.add_module('conv2', nn.Conv3d(bn_size * growth_rate, growth_rate, kernel_size=3, stride=1, padding=1, bias=False))
+def _bn_relu_conv(c_in, c_out, kernel, suffix="", **conv_kw):
+    """The pre-activation unit every part of the network is made of, as (name, module) pairs: BatchNorm3d -> ReLU ->
+    bias-free Conv3d.  `suffix` numbers the names inside a dense layer (norm1/relu1/conv1, norm2/...)."""
+    return [("norm" + suffix, nn.BatchNorm3d(c_in)), ("relu" + suffix, nn.ReLU(inplace=True)),
+            ("conv" + suffix, nn.Conv3d(c_in, c_out, kernel_size=kernel, stride=1, bias=False, **conv_kw))]
+
+
+class _Growth(nn.Sequential):
+    """One dense layer: a 1x1x1 bottleneck to bn_size * growth channels, a 3x3x3 convolution to `growth` new channels,
+    which are appended to the input (reference :10-41).  State-dict names norm1/conv1/norm2/conv2."""
+
+    def __init__(self, c_in, growth, bn_size, drop_rate):
+        mid = bn_size * growth
+        super().__init__(OrderedDict(_bn_relu_conv(c_in, mid, 1, "1") + _bn_relu_conv(mid, growth, 3, "2", padding=1)))
         self.drop_rate = drop_rate
 
     def forward(self, x):
-        new_features = super().forward(x)
+        fresh = nn.Sequential.forward(self, x)
         if self.drop_rate > 0:
-            new_features = F.dropout(new_features, p=self.drop_rate, training=self.training)
-        return torch.cat([x, new_features], 1)
+            fresh = F.dropout(fresh, p=self.drop_rate, training=self.training)
+        return torch.cat((x, fresh), dim=1)
 
 
-class _DenseBlock(nn.Sequential):
-    def __init__(self, num_layers, num_input_features, bn_size, growth_rate, drop_rate):
-        super().__init__()
-        for i in range(num_layers):
-            self.add_module('denselayer{}'.format(i + 1),
-                            _DenseLayer(num_input_features + i * growth_rate, growth_rate, bn_size, drop_rate))
+def _dense_block(n_layers, c_in, bn_size, growth, drop_rate):
+    """`denselayer1..n`, layer k reading the c_in + (k-1) * growth channels gathered so far (reference :44-52)."""
+    return nn.Sequential(OrderedDict((f"denselayer{k + 1}", _Growth(c_in + k * growth, growth, bn_size, drop_rate))
+                                     for k in range(n_layers)))
 
 
-class _Transition(nn.Sequential):
-    def __init__(self, num_input_features, num_output_features):
-        super().__init__()
-        self.add_module('norm', nn.BatchNorm3d(num_input_features))
-        self.add_module('relu', nn.ReLU(inplace=True))
-        self.add_module('conv', nn.Conv3d(num_input_features, num_output_features, kernel_size=1, stride=1, bias=False))
-        self.add_module('pool', nn.AvgPool3d(kernel_size=2, stride=2))
+def _transition(c_in, c_out):
+    """Channel halving + 2x2x2 average pool between dense blocks (reference :55-68)."""
+    return nn.Sequential(OrderedDict(_bn_relu_conv(c_in, c_out, 1) + [("pool", nn.AvgPool3d(kernel_size=2, stride=2))]))
+
+
+_INIT = {nn.Conv3d: lambda m: nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu'),
+         nn.BatchNorm3d: lambda m: (nn.init.ones_(m.weight), nn.init.zeros_(m.bias)),
+         nn.Linear: lambda m: nn.init.zeros_(m.bias)}
 
 
 class DenseNet(SegkNet):
@@ -63,35 +67,31 @@ class DenseNet(SegkNet):
         super().__init__()
         self.stem = dict(kernel=(conv1_t_size, 7, 7), stride=(conv1_t_stride, 2, 2), pad=(conv1_t_size // 2, 3, 3))
         self.no_max_pool, self.growth_rate, self.block_config, self.drop_rate = no_max_pool, growth_rate, tuple(block_config), drop_rate
-        feats = [('conv1', nn.Conv3d(n_input_channels, num_init_features, kernel_size=self.stem["kernel"], stride=self.stem["stride"],
+        # the whole feature extractor as one name -> module table (names and order are the checkpoint layout)
+        table = [("conv1", nn.Conv3d(n_input_channels, num_init_features, kernel_size=self.stem["kernel"], stride=self.stem["stride"],
                                      padding=self.stem["pad"], bias=False)),
-                 ('norm1', nn.BatchNorm3d(num_init_features)),
-                 ('relu1', nn.ReLU(inplace=True))]
+                 ("norm1", nn.BatchNorm3d(num_init_features)),
+                 ("relu1", nn.ReLU(inplace=True))]
         if not no_max_pool:
-            feats.append(('pool1', nn.MaxPool3d(kernel_size=3, stride=2, padding=1)))
-        self.features = nn.Sequential(OrderedDict(feats))
-        num_features = num_init_features
+            table.append(("pool1", nn.MaxPool3d(kernel_size=3, stride=2, padding=1)))
         self.block_io = []                       # (channels in, channels out) of every dense block
-        for i, num_layers in enumerate(block_config):
-            self.features.add_module('denseblock{}'.format(i + 1),
-                                     _DenseBlock(num_layers=num_layers, num_input_features=num_features, bn_size=bn_size,
-                                                 growth_rate=growth_rate, drop_rate=drop_rate))
-            self.block_io.append((num_features, num_features + num_layers * growth_rate))
-            num_features = num_features + num_layers * growth_rate
-            if i != len(block_config) - 1:
-                self.features.add_module('transition{}'.format(i + 1),
-                                         _Transition(num_input_features=num_features, num_output_features=num_features // 2))
-                num_features = num_features // 2
-        self.features.add_module('norm5', nn.BatchNorm3d(num_features))
-        self.classifier = nn.Linear(num_features, num_classes)
+        width = num_init_features
+        last = len(self.block_config) - 1
+        for b, n_layers in enumerate(self.block_config):
+            grown = width + n_layers * growth_rate
+            table.append((f"denseblock{b + 1}", _dense_block(n_layers, width, bn_size, growth_rate, drop_rate)))
+            self.block_io.append((width, grown))
+            width = grown
+            if b != last:
+                table.append((f"transition{b + 1}", _transition(width, width // 2)))
+                width //= 2
+        table.append(("norm5", nn.BatchNorm3d(width)))
+        self.features = nn.Sequential(OrderedDict(table))
+        self.classifier = nn.Linear(width, num_classes)
         for m in self.modules():
-            if isinstance(m, nn.Conv3d):
-                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
-            elif isinstance(m, nn.BatchNorm3d):
-                nn.init.constant_(m.weight, 1)
-                nn.init.constant_(m.bias, 0)
-            elif isinstance(m, nn.Linear):
-                nn.init.constant_(m.bias, 0)
+            init = _INIT.get(type(m))
+            if init is not None:
+                init(m)
 
     # -------------------------------------------------------------- CPU tensors: plain torch.nn
     def _forward_host(self, x):

@@ -47,8 +47,14 @@ class conv_block_nested(SegkBlock):
 
 
 class Nested_UNet(SegkNet):
-    def __init__(self, in_ch=1, out_ch=3):
+    """deep_supervision=False (default) is the reference's network: one 1x1 head `final` on x(0,4), same state_dict.
+    deep_supervision=True is an extension the reference does not contain (its file has a single head, :58,:81-82): the
+    UNet++ paper's four heads `final1..final4` on x(0,1)..x(0,4); forward returns the list of their logits and the
+    training loss is the sum of the per-head losses (`deep_supervision_loss`)."""
+
+    def __init__(self, in_ch=1, out_ch=3, deep_supervision=False):
         super().__init__()
+        self.deep_supervision = deep_supervision
         f = _WIDTHS
         self.pool = nn.MaxPool2d(kernel_size=2, stride=2)
         self.Up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
@@ -58,7 +64,11 @@ class Nested_UNet(SegkNet):
         for j in range(1, 5):
             for i in range(5 - j):
                 setattr(self, f"conv{i}_{j}", conv_block_nested(f[i] * j + f[i + 1], f[i], f[i]))
-        self.final = nn.Conv2d(f[0], out_ch, kernel_size=1)
+        if deep_supervision:
+            for j in range(1, 5):
+                setattr(self, f"final{j}", nn.Conv2d(f[0], out_ch, kernel_size=1))
+        else:
+            self.final = nn.Conv2d(f[0], out_ch, kernel_size=1)
 
     @staticmethod
     def _schedule():
@@ -76,7 +86,13 @@ class Nested_UNet(SegkNet):
                 node[i, 0] = block(x if i == 0 else self.pool(node[i - 1, 0]))
             else:
                 node[i, j] = block(torch.cat([node[i, k] for k in range(j)] + [self.Up(node[i + 1, j - 1])], 1))
+        if self.deep_supervision:
+            return [getattr(self, f"final{j}")(node[0, j]) for j in range(1, 5)]
         return self.final(node[0, 4])
+
+    def _pack_outputs(self, logits, feats):
+        # the tape hands back (head on x(0,4), [heads on x(0,1..3)]); callers get them shallowest first
+        return list(feats) + [logits]
 
     def _emit(self, rt, x):
         N, cin, H, W = x.shape
@@ -101,4 +117,19 @@ class Nested_UNet(SegkNet):
             else:
                 up = rt.up(node[i + 1, j - 1], align=True)
                 node[i, j] = block.emit(rt, f"conv{i}_{j}.", ([node[i, k] for k in range(j)], up), out=out)
+        if self.deep_supervision:
+            # the head on x(0,4) is the tape's main output; the three others leave as extra outputs whose gradients
+            # re-enter through the slices of the level-0 buffer that x(0,1..3) occupy
+            last = rt.head(node[0, 4], "final4.weight", "final4.bias")
+            return last, [rt.head(node[0, j], f"final{j}.weight", f"final{j}.bias") for j in range(1, 4)]
         return rt.head(node[0, 4], "final.weight", "final.bias")
+
+
+def deep_supervision_loss(outputs, target, criteria):
+    """Sum over the heads of the sum of `criteria` (callables loss(logits, target)): the deep-supervision objective."""
+    total = None
+    for logits in outputs:
+        for crit in criteria:
+            term = crit(logits, target)
+            total = term if total is None else total + term
+    return total

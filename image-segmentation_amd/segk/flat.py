@@ -11,6 +11,8 @@ BatchNorm statistics and loss normalisation, gradients averaged over ranks.
 The flat layout follows the order in which backward completes gradients (reverse registration order), so
 buckets fill front to back and the last, exposed bucket holds the small first-layer tensors.
 """
+import os
+
 import torch
 
 
@@ -36,9 +38,13 @@ class GradBuckets:
         for name in self.offsets:
             self.expected[self.bucket_of[name]] += 1
         self.world = 1
-        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+        initialised = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if group is not None or initialised:
             self.world = torch.distributed.get_world_size(group)
-        self.comm_stream = torch.cuda.Stream(device) if (device is not None and device.type == "cuda" and self.world > 1) else None
+        # SEGK_FORCE_COLLECTIVES=1: issue the collectives even in a one-rank group (a one-GPU box can then run the RCCL
+        # branch -- event, communication stream, all-reduce, scaling -- end to end; the result is the identity)
+        self.active = self.world > 1 or (initialised and os.environ.get("SEGK_FORCE_COLLECTIVES") == "1")
+        self.comm_stream = torch.cuda.Stream(device) if (device is not None and device.type == "cuda" and self.active) else None
         self.reset()
 
     def reset(self):
@@ -55,7 +61,7 @@ class GradBuckets:
 
     def _launch(self, b, flat_grad):
         self.launched.append(b)
-        if self.world == 1:
+        if not self.active:
             return
         import torch.distributed as dist
         lo, hi = self.ranges[b]
@@ -139,7 +145,7 @@ class FlatModel:
             gv = self.flat_grad[off:off + cnt].view_as(p)
             p.grad = gv
             self.views[n] = gv
-        if broadcast and self.buckets.world > 1:
+        if broadcast and self.buckets.active:
             import torch.distributed as dist
             dist.broadcast(self.flat_param, src=0, group=group)
             # frozen parameters and BatchNorm buffers: one coalesced broadcast per dtype instead of one per tensor

@@ -359,8 +359,12 @@ class RefDoubleConv(nn.Module):
 
 
 class RefNestedUNet(nn.Module):
-    def __init__(self, in_ch=1, out_ch=3):
+    """deep_supervision=True (heads final1..final4 on x(0,1)..x(0,4), list of logits) restates the UNet++ paper's deep
+    supervision in plain torch; the reference file has a single head, so that mode is NOT pinned by the reference."""
+
+    def __init__(self, in_ch=1, out_ch=3, deep_supervision=False):
         super().__init__()
+        self.deep_supervision = deep_supervision
         f = [64, 128, 256, 512, 1024]
         self.pool = nn.MaxPool2d(2, 2)
         self.Up = nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)
@@ -369,7 +373,11 @@ class RefNestedUNet(nn.Module):
         for j in range(1, 5):                                # nested columns
             for i in range(5 - j):
                 setattr(self, f"conv{i}_{j}", RefDoubleConv(f[i] * j + f[i + 1], f[i], f[i]))
-        self.final = nn.Conv2d(f[0], out_ch, 1)
+        if deep_supervision:
+            for j in range(1, 5):
+                setattr(self, f"final{j}", nn.Conv2d(f[0], out_ch, 1))
+        else:
+            self.final = nn.Conv2d(f[0], out_ch, 1)
 
     def forward(self, x):
         node = {}
@@ -380,6 +388,8 @@ class RefNestedUNet(nn.Module):
                 r = i - j
                 parts = [node[r, k] for k in range(j)] + [self.Up(node[r + 1, j - 1])]
                 node[r, j] = getattr(self, f"conv{r}_{j}")(torch.cat(parts, 1))
+        if self.deep_supervision:
+            return [getattr(self, f"final{j}")(node[0, j]) for j in range(1, 5)]
         return self.final(node[0, 4])
 
 

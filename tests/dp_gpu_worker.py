@@ -60,7 +60,44 @@ def main():
     dist.all_gather(both, w)
     assert torch.equal(both[0], both[1]), "ranks diverged after the optimizer step"
     print(f"rank {rank}: data-parallel gradients and parameters agree", flush=True)
+    vgg_against_the_oracle(rank, world)
     dist.destroy_process_group()
+
+
+def vgg_against_the_oracle(rank, world):
+    """UNetVgg itself, against the parity oracle of the data-parallel path: the CPU oracle run on every rank's own shard,
+    gradients averaged over the ranks.  The shards are the two well-conditioned batches (oracle/wellcond.py), on which
+    fp32 gradients are reproducible to 1e-5, so the all-reduced HIP gradients must meet 1e-4."""
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetvgg import UNetVgg
+    from oracle import ref_losses as RL
+    from oracle import wellcond as WC
+    from oracle.ref_models import RefUNetVgg, hash_init_
+    from segk.flat import FlatModel
+    x, t = WC.batch(WC.TAGS[rank % len(WC.TAGS)])
+    ref = WC.condition_(hash_init_(RefUNetVgg(out_classes=4))).train()
+    lr = ref(x)
+    (RL.dice_loss_sq(lr, t) + RL.focal_loss_with_logits(lr, t)).backward()
+    net = WC.condition_(hash_init_(UNetVgg(out_classes=4))).cuda().train()
+    flat = FlatModel(net)
+    assert len(flat.buckets.ranges) >= 4
+    lg = net(x.cuda())
+    (dice_loss_sq(lg, t.cuda()) + focal_loss_with_logits(lg, t.cuda())).backward()
+    torch.cuda.synchronize()
+    worst = 0.0
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        mine = q.grad.detach()
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        want = (sum(both) / world).double()
+        scale = float(want.norm())
+        if scale < 1e-6:      # analytically zero gradients: rounding noise
+            continue
+        err = float((p.grad.detach().cpu().double() - want).norm()) / scale
+        worst = max(worst, err)
+        assert err <= 1e-4, f"rank {rank}: {k}: rel-L2 {err:.3e} against the shard-averaged oracle gradients"
+    print(f"rank {rank}: UNetVgg all-reduced gradients match the shard-averaged oracle (worst rel-L2 {worst:.2e})", flush=True)
 
 
 if __name__ == "__main__":

@@ -128,6 +128,10 @@ def test_fp32_step_vs_golden(name, golden):
         gn = float(g[f"{name}/grad_norm/{k}"])
         if gn > 1e-6:   # loose band: the reference's own fp32 noise on these norms reaches ~1e-2 on tiny tensors
             assert abs(float(p.grad.double().norm()) - gn) / gn < 2e-2, f"{k}: grad norm {float(p.grad.norm())} vs {gn}"
+            # the first 16 values of the reference's gradient, within the same band relative to the tensor's norm
+            head = torch.from_numpy(g[f"{name}/grad_head/{k}"]).double()
+            got = p.grad.detach().flatten()[:head.numel()].double().cpu()
+            assert float((got - head).norm()) <= 2.5e-2 * gn, f"{k}: first gradient values {got[:4].tolist()} vs {head[:4].tolist()}"
     worst = check_fp32_grads(name, model)
     print(f"{name}: worst gradient rel-L2 vs fp64 oracle (hip, reference fp32, name) = {worst}")
     for k, b in model.named_buffers():
@@ -144,7 +148,7 @@ def test_fp32_step_vs_golden(name, golden):
     report(f"{name}/eval_logits", le[..., ::4, ::4].cpu(), torch.from_numpy(g[f"{name}/eval_logits_sub"]), rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["unetvgg_c4", "unetsimple_c4"])
+@pytest.mark.parametrize("name", ["unetvgg_c4", "unetsimple_c4", "nestedunet_c4", "unetvgg_c4_convtrans"])
 def test_bf16_step_vs_golden(name, golden):
     """bf16 path.  Every kernel is within rel 2e-2 of its fp32 op (tests/test_gpu_ops.py); end to end, 25 stacked
     layers accumulate more than that in ANY bf16 implementation, so the network-level bound is the error of
@@ -194,8 +198,15 @@ def test_unetvgg384_fp32_mask(golden):
     report("unetvgg384/loss", loss.cpu(), torch.from_numpy(g["unetvgg384/loss"]), rtol=1e-4, atol=1e-6)
     mask = logits.argmax(1).to(torch.uint8).cpu()
     ref = torch.from_numpy(g["unetvgg384/mask"])
+    # logits agree to 1e-4 (checked above on the sub-sampled grid), so wherever the top-2 margin of the HIP logits
+    # exceeds 4e-4 the arg-max is decided: there every pixel must equal the reference mask; elsewhere at most the
+    # near-tie pixels may differ
+    top2 = logits.cpu().topk(2, dim=1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 4e-4
+    assert torch.equal(mask[safe], ref[safe]), f"{int((mask[safe] != ref[safe]).sum())} decided pixels differ"
     diff = int((mask != ref).sum())
-    assert diff <= int(g["unetvgg384/near_tie_1e-3"]), f"{diff} mask pixels differ"
+    print(f"unetvgg384: {diff} of {mask.numel()} mask pixels differ; {int((~safe).sum())} pixels have a margin below 4e-4")
+    assert diff <= int((~safe).sum()) and diff <= int(g["unetvgg384/near_tie_1e-3"]), f"{diff} mask pixels differ"
     for k, p in model.named_parameters():
         gn = float(g[f"unetvgg384/grad_norm/{k}"])
         if gn > 1e-6:     # band = the reference's own fp32 noise on these norms (see check_grads_at_reference_noise_floor)
@@ -381,3 +392,103 @@ def test_resizing_wrappers_vs_golden(name):
         gn = float(g[f"{name}/grad_norm/{k}"])
         if gn > 1e-6:
             assert abs(float(p.grad.double().norm()) - gn) / gn < 2e-2, f"{k}: grad norm {float(p.grad.norm())} vs {gn}"
+
+
+def _deep_sup_pair(dtype):
+    """UNet++ with four supervised heads (an extension: the reference has one head, so the oracle for it is this
+    repository's own torch restatement, NOT pinned by the reference), summed Dice + focal over the heads."""
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetplusplus import Nested_UNet, deep_supervision_loss
+    from oracle import ref_losses as RL
+    from oracle import ref_models as RM
+    x, t = RM.synthetic_batch(2, 64, 4, in_ch=1, tag="model:nestedunet_deepsup")
+    ref = RM.hash_init_(RM.RefNestedUNet(in_ch=1, out_ch=4, deep_supervision=True)).double().train()
+    outs_r = ref(x.double())
+    loss_r = deep_supervision_loss(outs_r, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
+    loss_r.backward()
+    net = RM.hash_init_(Nested_UNet(in_ch=1, out_ch=4, deep_supervision=True)).cuda().train().set_compute_dtype(dtype)
+    outs = net(x.cuda())
+    loss = deep_supervision_loss(outs, t.cuda(), [dice_loss_sq, focal_loss_with_logits])
+    loss.backward()
+    torch.cuda.synchronize()
+    return net, outs, loss, ref, outs_r, loss_r
+
+
+def test_nestedunet_deep_supervision_fp32():
+    net, outs, loss, ref, outs_r, loss_r = _deep_sup_pair(torch.float32)
+    assert isinstance(outs, list) and len(outs) == 4
+    for j, (o, r) in enumerate(zip(outs, outs_r)):
+        report(f"deepsup/head{j + 1}", o.detach().cpu(), r.detach(), rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - float(loss_r)) < 1e-4 * max(1.0, abs(float(loss_r)))
+    worst = 0.0
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        scale = float(q.grad.norm())
+        if scale < 1e-6:
+            assert float(p.grad.norm()) < 1e-5, k
+            continue
+        e = float((p.grad.double().cpu() - q.grad).norm()) / scale
+        worst = max(worst, e)
+        # heads sit behind the last ReLU: 1e-4; deeper tensors carry the ReLU-mask flips of a random-weight network
+        assert e <= (1e-4 if k.startswith("final") else 2.5e-2), (k, e)
+    print(f"deep supervision fp32: worst gradient rel-L2 vs fp64 oracle {worst:.3e}")
+
+
+def test_nestedunet_deep_supervision_bf16():
+    net, outs, loss, ref, outs_r, loss_r = _deep_sup_pair(torch.bfloat16)
+    for j, (o, r) in enumerate(zip(outs, outs_r)):
+        e = rel_l2(o, r)
+        assert e < 5e-2, (j, e)          # network-level bf16 bound, as for the single-head network
+    assert abs(float(loss) - float(loss_r)) < 2e-2 * abs(float(loss_r))
+    for k in ("final1", "final2", "final3", "final4"):
+        p, q = dict(net.named_parameters())[k + ".weight"], dict(ref.named_parameters())[k + ".weight"]
+        assert rel_l2(p.grad, q.grad) < 1e-1, k
+
+
+@pytest.mark.parametrize("tag", ["wellcond:8", "wellcond:7"])
+def test_fp32_gradients_meet_1e4_on_well_conditioned_cases(tag):
+    """End-to-end fp32 gradient parity at the north-star bound.  On the well-conditioned cases (oracle/wellcond.py: no
+    pre-ReLU value within rounding of its threshold, so no ReLU mask depends on the rounding) every parameter gradient of the
+    HIP path must be within 1e-4 (relative L2) of the REFERENCE's fp32 gradient: against the reference-generated fixture
+    (norm, 4096 strided samples and four +-1 hash projections per tensor: tests/golden/wellcond.npz) and, tensor for tensor,
+    against the oracle run here (pinned bit for bit to the reference on these cases)."""
+    import os
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetvgg import UNetVgg
+    from oracle import ref_losses as RL
+    from oracle import ref_models as RM
+    from oracle import wellcond as WC
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wellcond.npz"))
+    x, t = WC.batch(tag)
+    net = WC.condition_(RM.hash_init_(UNetVgg(out_classes=4))).cuda().train().set_compute_dtype(torch.float32)
+    lg = net(x.cuda())
+    loss = dice_loss_sq(lg, t.cuda()) + focal_loss_with_logits(lg, t.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    report(f"{tag}/logits", lg.detach().cpu(), torch.from_numpy(g[f"{tag}/logits"]), rtol=1e-4, atol=1e-4)
+    assert abs(float(loss) - float(g[f"{tag}/loss"])) <= 1e-4 * abs(float(g[f"{tag}/loss"]))
+    ref = WC.condition_(RM.hash_init_(RM.RefUNetVgg(out_classes=4))).train()
+    lr = ref(x)
+    (RL.dice_loss_sq(lr, t) + RL.focal_loss_with_logits(lr, t)).backward()
+    worst = 0.0
+    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        got = p.grad.detach().double().flatten().cpu()
+        norm = float(g[f"{tag}/grad/{k}/norm"])
+        if norm < 1e-6:       # analytically zero (a bias in front of a batch-statistics norm): rounding noise in the reference
+            assert float(got.norm()) < 1e-5, k
+            continue
+        assert abs(float(got.norm()) - norm) <= 1e-4 * norm, k
+        sub = torch.from_numpy(g[f"{tag}/grad/{k}/sub"]).double()
+        stride = max(1, got.numel() // 4096)
+        share = (sub.numel() / got.numel()) ** 0.5                     # the samples' share of the tensor's norm
+        assert float((got[::stride][:4096] - sub).norm()) <= 1e-4 * norm * max(share, 1e-2) * 4 + 1e-12, k
+        for i, want in enumerate(g[f"{tag}/grad/{k}/proj"]):
+            sign = RM.hash_uniform(f"proj{i}:{k}", (got.numel(),), -1, 1).sign().double()
+            assert abs(float(got @ sign) - float(want)) <= 4e-4 * norm, (k, i)
+        err = float((got - q.grad.double().flatten()).norm()) / norm
+        worst = max(worst, err)
+        assert err <= 1e-4, f"{k}: rel-L2 {err:.3e} against the reference's fp32 gradient"
+    print(f"{tag}: worst gradient rel-L2 against the reference's fp32 gradients {worst:.2e} "
+          f"(reference fp32 vs fp64: {float(g[tag + '/reference_fp32_vs_fp64_worst_grad_rel_l2']):.2e}; smallest relative "
+          f"pre-ReLU margin {float(g[tag + '/min_relu_margin']):.1e})")

@@ -328,3 +328,51 @@ def test_gpu_tensors_never_fall_back(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(_lib.SegkError, match="missing"):
         _lib.lib()
+
+
+def test_nestedunet_deep_supervision_host_path_equals_oracle():
+    """Four-head UNet++ (an extension the reference does not contain; oracle = this repository's torch restatement, not
+    pinned by the reference): the product's CPU path and the oracle agree bit for bit, and the default network keeps
+    the reference's single `final` head."""
+    import torch
+    from models.unetplusplus import Nested_UNet, deep_supervision_loss
+    from oracle import ref_losses as RL
+    from oracle import ref_models as RM
+    x, t = RM.synthetic_batch(1, 32, 4, in_ch=1, tag="deepsup-cpu")
+    a = RM.hash_init_(Nested_UNet(in_ch=1, out_ch=4, deep_supervision=True)).train()
+    b = RM.hash_init_(RM.RefNestedUNet(in_ch=1, out_ch=4, deep_supervision=True)).train()
+    assert [k for k in a.state_dict() if k.startswith("final")] == [f"final{j}.{w}" for j in range(1, 5) for w in ("weight", "bias")]
+    oa, ob = a(x), b(x)
+    assert len(oa) == 4 and all(torch.equal(p, q) for p, q in zip(oa, ob))
+    la = deep_supervision_loss(oa, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
+    lb = deep_supervision_loss(ob, t, [RL.dice_loss_sq, RL.focal_loss_with_logits])
+    assert torch.equal(la, lb)
+    assert "final.weight" in Nested_UNet(in_ch=1, out_ch=4).state_dict() and "final1.weight" not in Nested_UNet().state_dict()
+
+
+def test_oracle_reproduces_the_well_conditioned_fixture():
+    """tests/golden/wellcond.npz comes from the reference import (oracle/make_golden_wellcond.py); the oracle must give the
+    same logits, loss and gradient summaries bit for bit, and the pin file must say so."""
+    import json
+    import os
+    import numpy as np
+    import torch
+    from oracle import ref_losses as RL
+    from oracle import ref_models as RM
+    from oracle import wellcond as WC
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(root, "wellcond.npz"))
+    pins = json.load(open(os.path.join(root, "oracle_pin.json")))["checks"]
+    tag = WC.TAGS[0]
+    assert pins[f"model/{tag}"] is True and pins[f"model/{WC.TAGS[1]}"] is True
+    x, t = WC.batch(tag)
+    m = WC.condition_(RM.hash_init_(RM.RefUNetVgg(out_classes=4))).train()
+    lg = m(x)
+    loss = RL.dice_loss_sq(lg, t) + RL.focal_loss_with_logits(lg, t)
+    loss.backward()
+    assert np.array_equal(lg.detach().numpy(), g[f"{tag}/logits"]) and float(loss) == float(g[f"{tag}/loss"])
+    for k, p in m.named_parameters():
+        flat = p.grad.flatten()
+        stride = max(1, flat.numel() // 4096)
+        assert np.array_equal(flat[::stride][:4096].numpy(), g[f"{tag}/grad/{k}/sub"]), k
+    assert float(g[f"{tag}/min_relu_margin"]) > 1e-6 and float(g[f"{tag}/reference_fp32_vs_fp64_worst_grad_rel_l2"]) < 2e-5
