@@ -387,13 +387,13 @@ def main():
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             # HBM bytes of the same launches (one step) from the committed PMC passes of this workload; null for other workloads
             traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+            tfile = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
             if args.model == "unetvgg" and args.dtype == "bf16" and args.batch == 32 and args.side == 384 and os.path.exists(tfile):  # noqa: E501
                 with open(tfile) as f:
                     traffic = json.load(f).get("conv_mfma_kernels_hbm_bytes_per_step")
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
                                "frac": round(achieved / peak, 4), "traffic": traffic,
-                               "traffic_note": ("HBM bytes per step of these launches (rocprofv3 PMC, profiles/r01_hbm_traffic.json); "
+                               "traffic_note": ("HBM bytes per step of these launches (rocprofv3 PMC, profiles/r02_hbm_traffic.json); "
                                                 f"algorithmic minimum {ALGO_CONV_GB_PER_STEP} GB") if traffic else None,
                                "kernel": "conv_fwd_kernel + conv_wgrad_kernel (all MFMA convolution launches of a step)",
                                "launches_per_step": len(timer) // timed_steps, "conv_ms_per_step": round(conv_ms, 3),

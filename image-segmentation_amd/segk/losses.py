@@ -88,11 +88,17 @@ def _as_square_labels(act):
 _SHARED = {}
 
 
+def _same_data(a, b):
+    """Two tensor objects over the same elements (the Dice entry point hands the kernels a reshaped view of the labels)."""
+    return (a is b) or (a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride() and a.dtype == b.dtype
+                        and a._version == b._version)
+
+
 def _shared_lookup(pred, target, gamma, alpha, flags, grad):
     e = _SHARED.get("entry")
     if e is None or e["token"]["spent"]:
         return None
-    if e["pred"]() is not pred or e["target"]() is not target or e["versions"] != (pred._version, target._version):
+    if e["pred"]() is not pred or e["versions"] != (pred._version, target._version) or not _same_data(e["target"], target):
         return None
     if e["key"] != (float(gamma), None if alpha is None else id(alpha), flags, grad):
         return None
@@ -115,7 +121,9 @@ def dice_focal(pred, target, gamma=2.0, alpha=None, no_sft=False, is_all_chann=F
         outs = _DiceFocalFn.apply(pred, target, gamma, alpha, flags, False)
     finally:
         _SHARED["pending"] = None
-    _SHARED["entry"] = {"pred": weakref.ref(pred), "target": weakref.ref(target), "versions": (pred._version, target._version),
+    # the logits are held weakly (large, and only the caller's own tensor can match again); the target strongly: the entry
+    # points pass views of it, and it is small
+    _SHARED["entry"] = {"pred": weakref.ref(pred), "target": target, "versions": (pred._version, target._version),
                         "key": (float(gamma), None if alpha is None else id(alpha), flags, grad), "token": token, "outs": outs}
     return outs
 

@@ -226,3 +226,32 @@ def test_unsquared_dice_metric_vs_golden():
         probs = torch.softmax(z, 1)
         report(f"{name}/dice_old_nosft", dice_coefficientold(probs.cuda(), t.cuda(), nosft=True).cpu(), torch.from_numpy(g[f"{name}/dice_old"]),
                rtol=1e-5, atol=1e-6)
+
+
+def test_dice_plus_focal_run_one_forward_and_one_backward_pass():
+    """`dice_loss_sq(out, t) + focal_loss_with_logits(out, t)` (the training loops' loss) shares one autograd node: two
+    C-ABI calls forward (sums + finalize), one backward, and the same values and gradient as the two losses taken apart."""
+    import torch
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from segk import _lib
+    g = torch.Generator().manual_seed(5)
+    z = torch.randn(3, 4, 48, 48, generator=g).cuda().requires_grad_(True)
+    t = torch.randint(0, 4, (3, 48, 48), generator=g).cuda()
+    before = _lib.launches
+    d, f = dice_loss_sq(z, t), focal_loss_with_logits(z, t)
+    (d + f).backward()
+    assert _lib.launches - before == 3, _lib.launches - before
+    apart = []
+    for fn in (dice_loss_sq, focal_loss_with_logits):
+        z2 = z.detach().clone().requires_grad_(True)
+        v = fn(z2, t)
+        v.backward()
+        apart.append((v.detach(), z2.grad))
+    assert float(apart[0][0]) == float(d) and float(apart[1][0]) == float(f)
+    want = apart[0][1] + apart[1][1]
+    assert float((z.grad - want).abs().max()) <= 1e-7 + 1e-5 * float(want.abs().max())
+    # a node that has run its backward is not handed out again
+    before = _lib.launches
+    focal_loss_with_logits(z, t).backward()
+    assert _lib.launches - before == 3
