@@ -182,8 +182,9 @@ def main():
                     help="launcher self-test: rendezvous of the N ranks on the CPU (gloo), no GPU work, prints the rank count")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--wgrad-stream", action="store_true",
-                    help="weight gradients on a second HIP stream next to the data gradients (off on the steps whose launches are event-timed)")
+    ap.add_argument("--no-wgrad-stream", action="store_true",
+                    help="keep the weight gradients on the main stream (default: on a second HIP stream next to the data gradients, "
+                         "except on the steps whose launches are event-timed and with more than one rank)")
     args = ap.parse_args()
     if os.environ.get("SEGK_BENCH_TRACE_AFTER"):      # debugging aid: dump every thread's Python stack and exit if still running after N seconds
         import faulthandler
@@ -291,7 +292,7 @@ def main():
         torch.cuda.synchronize()
 
     from segk import engine
-    engine._WGRAD_STREAM = args.wgrad_stream or engine._WGRAD_STREAM
+    engine._WGRAD_STREAM = engine._WGRAD_STREAM and not args.no_wgrad_stream
     overlap = engine._WGRAD_STREAM
     for _ in range(args.warmup):
         step()

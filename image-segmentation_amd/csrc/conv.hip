@@ -101,17 +101,23 @@ template <> struct Mma<float> {
 // Diagnostic build only (make probe): shader-clock and 100 MHz real-time stamps around the main loop of the first
 // workgroups, written to a buffer nothing else reads; the ratio is the clock the chip holds inside the kernel.
 __device__ unsigned long long g_clock_probe[1024][4];
+#define SEGK_PROBE_ENTRY() const unsigned long long probe_e = __builtin_amdgcn_s_memtime();
 #define SEGK_PROBE_BEGIN()                                                                              \
     unsigned long long probe_t0 = 0, probe_r0 = 0;                                                      \
-    if (threadIdx.x == 0 && blockIdx.x < 1024) { probe_t0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
+    if (threadIdx.x == 0 && blockIdx.x < 1024) { probe_t0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); \
+        g_clock_probe[blockIdx.x][2] = probe_t0 - probe_e; }
+#define SEGK_PROBE_EXIT()                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < 1024) g_clock_probe[blockIdx.x][3] = __builtin_amdgcn_s_memtime() - probe_e;
 #define SEGK_PROBE_END()                                                                                \
     if (threadIdx.x == 0 && blockIdx.x < 1024) {                                                        \
         g_clock_probe[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - probe_t0;                         \
         g_clock_probe[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - probe_r0;                     \
     }
 #else
+#define SEGK_PROBE_ENTRY()
 #define SEGK_PROBE_BEGIN()
 #define SEGK_PROBE_END()
+#define SEGK_PROBE_EXIT()
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -158,6 +164,7 @@ __device__ __forceinline__ unsigned lds_address(const void* p) {
 // (the last K-row is peeled), so a K-row is one straight-line block of 9 taps.
 template <typename T, int TAPS, int TH, int BN, int WPX_WAVES, int WCO_WAVES, int WGS = 2, bool PIPE = false>
 __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_WAVES * WCO_WAVES)) void conv_fwd_kernel(const ConvArgs a) {
+    SEGK_PROBE_ENTRY();
     constexpr bool ONE_HALO = WGS > 2;
     static_assert(!PIPE || (!ONE_HALO && sizeof(T) == 2), "the skewed loop is built for bf16 with two halo buffers");
     constexpr int NT = 64 * WPX_WAVES * WCO_WAVES;   // threads: 4 waves (two workgroups per CU) or 8 waves (one)
@@ -482,6 +489,7 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
                 Elem<T>::store8(dst, v);
             }
         }
+        SEGK_PROBE_EXIT();
         return;
     }
     // Epilogue of a convolution in front of a normalisation (single destination, no mask, no accumulation): besides
@@ -530,6 +538,7 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
             *reinterpret_cast<float4*>(dst + a.Cout + 4) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
         }
     }
+    SEGK_PROBE_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,8 +20,9 @@ from .ops import Act
 
 _NO_CONV_STATS = bool(os.environ.get("SEGK_NO_CONV_STATS"))   # experiments: separate statistics pass after every convolution
 # Weight gradients on a second stream: a convolution's weight and data gradients only share their input dy, so the two
-# kernels can run side by side and fill each other's tails and the under-occupied small layers.
-_WGRAD_STREAM = os.environ.get("SEGK_WGRAD_STREAM", "0") == "1"
+# kernels can run side by side and fill each other's tails and the under-occupied small layers (gradients are bitwise
+# the same either way).  On by default with one rank; SEGK_WGRAD_STREAM=0 turns it off.
+_WGRAD_STREAM = os.environ.get("SEGK_WGRAD_STREAM", "1") == "1"
 _side_streams = {}
 
 
