@@ -32,6 +32,10 @@ _PROTOS = {
     "segk_edge_bwd": (I, [P, P, P, L, L, L, P, P, Z, I, P]),
     "segk_nchw_to_nhwc": (I, [P, L, L, L, L, P, I, L, L, I, P]),
     "segk_im2col3x3": (I, [P, L, L, L, L, P, I, L, L, I, P]),
+    "segk_conv_first_stat_rows": (L, [L, L, L]),
+    "segk_conv_first_fwd": (I, [P, L, L, L, L, P, P, L, P, I, L, P, I, I, P]),
+    "segk_conv_first_wgrad_workspace": (Z, [L, L, L]),
+    "segk_conv_first_wgrad": (I, [P, L, L, L, L, P, I, L, L, P, I, P, Z, I, P]),
     "segk_conv_krow": (I, [I]),
     "segk_conv_packed_bytes": (Z, [I, L, L, I, L]),
     "segk_conv_pack": (I, [P, L, L, I, L, I, P, P, I, P]),

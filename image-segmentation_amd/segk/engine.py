@@ -18,6 +18,7 @@ from . import ops
 from .ops import Act
 
 
+_NO_FIRST_DIRECT = bool(os.environ.get("SEGK_NO_FIRST_DIRECT"))   # experiments: first convolution as a 1x1 convolution over a patch image
 _NO_CONV_STATS = bool(os.environ.get("SEGK_NO_CONV_STATS"))   # experiments: separate statistics pass after every convolution
 # Weight gradients on a second stream: a convolution's weight and data gradients only share their input dy, so the two
 # kernels can run side by side and fill each other's tails and the under-occupied small layers (gradients are bitwise
@@ -231,21 +232,34 @@ class Runtime:
         w = self.p[wname]
         Cout, Cin = w.shape[0], w.shape[1]
         cs = (Cout + 7) // 8 * 8
-        patches = ops.im2col3x3(x, self.dtype)
-        w1 = torch.zeros(cs, 9 * Cin, 1, 1, dtype=torch.float32, device=self.device)
-        w1[:Cout] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
-        wf, _ = ops.conv_pack(w1, self.dtype, want_bwd=False)
         N, _, H, W = x.shape
         y = Var(self.new(N, H, W, cs))
-        ops.conv_fwd(patches, wf, cs, y.act, taps=1, bias=self._bias(bname, cs),
-                     stat_partials=self._stat_buffer(y, stats, norm_groups=N if stats == "instance" else None))
+        direct = ops.conv_first_direct_ok(x, Cout, self.dtype) and not _NO_FIRST_DIRECT
+        if direct:
+            # straight from the image: no patch image in the forward pass (the weight gradient gathers it when it runs)
+            want = bool(stats) and (stats == "instance" or self.training) and not _NO_CONV_STATS
+            y.stat_part = ops.conv_first_fwd(x, w, self._bias(bname), y.act, want_stats=want)
+            patches = None
+        else:
+            patches = ops.im2col3x3(x, self.dtype)
+            w1 = torch.zeros(cs, 9 * Cin, 1, 1, dtype=torch.float32, device=self.device)
+            w1[:Cout] = w.detach().permute(0, 2, 3, 1).reshape(Cout, 9 * Cin, 1, 1)
+            wf, _ = ops.conv_pack(w1, self.dtype, want_bwd=False)
+            ops.conv_fwd(patches, wf, cs, y.act, taps=1, bias=self._bias(bname, cs),
+                         stat_partials=self._stat_buffer(y, stats, norm_groups=N if stats == "instance" else None))
 
         def bwd():
+            nonlocal patches
             dy = self.grad_of(y.act)
-            dw = torch.empty(cs, 9 * Cin, dtype=torch.float32, device=self.device)
-            ops.conv_wgrad(patches, dy, dw, taps=1, cin_real=9 * Cin)
             g = self.alloc_grad(wname, w)
-            g.copy_(dw[:Cout].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2))
+            if direct and Cout == 64 and g.is_contiguous():
+                ops.conv_first_wgrad(x, dy, g)               # straight from the image into the gradient tensor
+            else:
+                if patches is None:
+                    patches = ops.im2col3x3(x, self.dtype)
+                dw = torch.empty(cs, 9 * Cin, dtype=torch.float32, device=self.device)
+                ops.conv_wgrad(patches, dy, dw, taps=1, cin_real=9 * Cin)
+                g.copy_(dw[:Cout].view(Cout, 3, 3, Cin).permute(0, 3, 1, 2))
             self._emit(wname, g)
             if bname is not None:
                 gb = self.alloc_grad(bname, self.p[bname])

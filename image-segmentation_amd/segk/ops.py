@@ -122,6 +122,40 @@ def im2col3x3(x, dtype):
     return out
 
 
+def conv_first_direct_ok(x, Cout, dtype):
+    """The direct first-layer kernel serves bf16 outputs of 32 or 64 channels from images with up to 3 channels."""
+    return dtype == torch.bfloat16 and x.shape[1] <= 3 and Cout in (32, 64)
+
+
+def conv_first_fwd(x, w, bias, out, relu=False, want_stats=False):
+    """out (bf16 NHWC Act) = bias + conv3x3(x, w) straight from the fp32 NCHW image x; -> statistics partials or None."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    assert out.C == Cout and out.dtype == torch.bfloat16 and (out.N, out.H, out.W) == (N, H, W)
+    x = x.contiguous().float()
+    part = None
+    if want_stats:
+        part = torch.empty(query("segk_conv_first_stat_rows", N, H, W), 2, Cout, dtype=torch.float32, device=x.device)
+    dev, st = _env(x)
+    with _Timed("conv_fwd", 2.0 * N * H * W * Cout * 32, "first layer"):
+        call("segk_conv_first_fwd", x.data_ptr(), N, Cin, H, W, w.detach().contiguous().data_ptr(), _p(bias), Cout, out.ptr,
+             dt(out.dtype), out.ld, _p(part), RELU if relu else 0, dev, st)
+    return part
+
+
+def conv_first_wgrad(x, dy, dw, accumulate=False):
+    """dw (fp32 [64, Cin, 3, 3]) = weight gradient of the first convolution from the fp32 NCHW image x and dy (bf16 Act)."""
+    N, Cin, H, W = x.shape
+    assert dy.C == 64 and dy.dtype == torch.bfloat16 and tuple(dw.shape) == (64, Cin, 3, 3) and dw.is_contiguous()
+    x = x.contiguous().float()
+    dev, st = _env(x)
+    ws = workspace(query("segk_conv_first_wgrad_workspace", N, H, W), x.device)
+    with _Timed("conv_wgrad", 2.0 * N * H * W * 64 * 32, "first layer"):
+        call("segk_conv_first_wgrad", x.data_ptr(), N, Cin, H, W, dy.ptr, dt(dy.dtype), dy.ld, 64, dw.data_ptr(),
+             ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
+    return dw
+
+
 def nchw_to_nhwc(x, dtype, C=None):
     N, Cin, H, W = x.shape
     C = C or (Cin + 7) // 8 * 8

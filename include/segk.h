@@ -113,6 +113,27 @@ int segk_nchw_to_nhwc(const float* src, int64_t N, int64_t Cin, int64_t H, int64
 int segk_im2col3x3(const float* src, int64_t N, int64_t Cin, int64_t H, int64_t W, void* dst,
                    int dst_dtype, int64_t Cout, int64_t ld, int dev, void* stream);
 
+/* The first convolution computed straight from the image: y = bias + conv3x3(x, w) for an fp32 NCHW image with 1..3
+ * channels and the module's fp32 [Cout, Cin, 3, 3] weight, Cout in {32, 64}, bf16 NHWC output (no patch image, no
+ * packed weights: the 9*Cin <= 27 products of a pixel are ONE 32-deep matrix step).
+ * replaces: nn.Conv2d(3, 64, 3, padding=1) forward, models/unetvgg.py:72 (VGG features[0]); nn.Conv2d(in_ch, 64, 3,
+ *           padding=1), models/unetplusplus.py:11,45.
+ * flags bit0: ReLU.  stat_partials (optional, fp32 [segk_conv_first_stat_rows(N,H,W)][2][Cout]): per-wave sums and sums
+ * of squares of the stored output, consumed by segk_norm_stats_finalize like those of segk_conv_fwd.          */
+int64_t segk_conv_first_stat_rows(int64_t N, int64_t H, int64_t W);
+int segk_conv_first_fwd(const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const float* w, const float* bias,
+                        int64_t Cout, void* y, int y_dtype, int64_t ldy, float* stat_partials, int flags, int dev,
+                        void* stream);
+
+/* Weight gradient of that first convolution, again straight from the image: dw (fp32, the module's [64, Cin, 3, 3]
+ * layout) = sum over pixels of dy (bf16 NHWC, 64 channels) x the 3x3 neighbourhood of x; per-workgroup partial blocks
+ * are added in fixed order (deterministic).  flags bit1: dw += result.
+ * replaces: the weight-gradient half of that Conv2d's backward (the image needs no data gradient).             */
+size_t segk_conv_first_wgrad_workspace(int64_t N, int64_t H, int64_t W);
+int segk_conv_first_wgrad(const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const void* dy, int dy_dtype,
+                          int64_t ld_dy, int64_t Cout, float* dw, int flags, void* workspace, size_t workspace_bytes, int dev,
+                          void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Convolutions on the matrix cores.
  * ---------------------------------------------------------------------------------------------- */

@@ -222,6 +222,57 @@ def test_first_conv_im2col(dtype):
     report("first_conv_wgrad", got, ref, rtol=TOL[dtype]["rtol"], atol=TOL[dtype]["atol"] * float(ref.abs().max()) * 0.05)
 
 
+@pytest.mark.parametrize("case", [(2, 24, 32, 3, 64), (1, 40, 72, 1, 64), (3, 9, 130, 3, 32), (1, 64, 64, 2, 64)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_first_conv_direct(case):
+    """The first convolution straight from the fp32 image (bf16 output): values, ReLU flag, and the per-wave statistics
+    partials (sums / sums of squares of what was stored).  Image sizes that do not fill the 8 x 64 workgroup tiles."""
+    from segk import ops
+    N, H, W, Cin, Cout = case
+    x = rnd((N, Cin, H, W), torch.float32, 31)
+    w = rnd((Cout, Cin, 3, 3), torch.bfloat16, 32, scale=0.2)
+    b = rnd((Cout,), torch.float32, 33)
+    assert ops.conv_first_direct_ok(x, Cout, torch.bfloat16) and not ops.conv_first_direct_ok(x, Cout, torch.float32)
+    ref = F.conv2d(x.bfloat16().double(), w.double(), b.double(), padding=1).float()
+    for relu in (False, True):
+        buf = torch.full((N, H, W, Cout + 8), 7.0, dtype=torch.bfloat16, device="cuda")
+        out = ops.Act(buf, 8, Cout)                      # a channel slice of a wider buffer
+        part = ops.conv_first_fwd(x.cuda(), w.cuda(), b.cuda(), out, relu=relu, want_stats=True)
+        want = ref.clamp_min(0) if relu else ref
+        report("first_conv_direct", from_act(out), want, **TOL[torch.bfloat16])
+        assert float(buf[..., :8].float().min()) == 7.0  # neighbouring channels untouched
+        stored = from_act(out).double()
+        sums = part.double().sum(0).cpu()                # [2, Cout]
+        report("first_conv_direct/sum", sums[0], stored.sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+        report("first_conv_direct/sumsq", sums[1], (stored * stored).sum((0, 2, 3)), rtol=1e-5, atol=1e-3)
+        assert part.shape[0] % N == 0                    # rows are grouped per image (instance statistics)
+        per = part.shape[0] // N
+        report("first_conv_direct/sum[n=0]", part[:per].double().sum(0).cpu()[0], stored[0].sum((1, 2)), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("case", [(2, 24, 32, 3), (1, 40, 72, 1), (3, 9, 130, 3), (1, 64, 64, 2), (20, 64, 96, 3)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_first_conv_direct_wgrad(case):
+    """Weight gradient of the first convolution straight from the image (many tiles per workgroup in the last case),
+    against ATen on the bf16-rounded operands; accumulate flag; run-to-run bitwise reproducible."""
+    from segk import ops
+    N, H, W, Cin = case
+    Cout = 64
+    x = rnd((N, Cin, H, W), torch.float32, 41)
+    dy = rnd((N, Cout, H, W), torch.bfloat16, 42)
+    ref = torch.nn.grad.conv2d_weight(x.bfloat16().double(), (Cout, Cin, 3, 3), dy.double(), padding=1).float()
+    dya = to_act(dy, torch.bfloat16, ld=Cout + 8, c0=8)
+    dw = torch.full((Cout, Cin, 3, 3), 3.0, device="cuda")
+    ops.conv_first_wgrad(x.cuda(), dya, dw)
+    tol = dict(rtol=2e-2, atol=2e-2 * float(ref.abs().max()) * 0.05)
+    report("first_conv_direct_wgrad", dw.cpu(), ref, **tol)
+    again = torch.empty_like(dw)
+    ops.conv_first_wgrad(x.cuda(), dya, again)
+    assert torch.equal(dw, again)
+    ops.conv_first_wgrad(x.cuda(), dya, again, accumulate=True)
+    report("first_conv_direct_wgrad/accumulate", again.cpu(), 2 * ref, rtol=2e-2, atol=2 * tol["atol"])
+
+
 # ---------------------------------------------------------------------------------------- norms
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(4, 64, 24, 24), (2, 256, 8, 16), (3, 32, 48, 48), (2, 40, 12, 20)], ids=str)
