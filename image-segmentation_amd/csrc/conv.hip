@@ -65,6 +65,12 @@ struct ConvArgs {
     int depth = 0, nkd = 3;
     int64_t slice_bytes = 0;          // bytes between consecutive slices of the input
     float* stat_part = nullptr;       // optional [N*tiles][pixel-wave][2][Cout]: per-wave sum / sum of squares of the stored output
+    // Data gradient whose output is the gradient of relu(norm(z)): the epilogue also produces the two sums the norm's
+    // backward needs (sum g, sum g*zhat with g masked by the ReLU), rows laid out as stat_part's.
+    const char* nb_z = nullptr; int64_t nb_ldz = 0;   // z: what the norm read, same pixels and channels as the output
+    const float* nb_stats = nullptr;                  // [Cout][2] mean, 1/std
+    const float* nb_gamma = nullptr; const float* nb_beta = nullptr;
+    float* nb_part = nullptr;
 };
 
 __device__ __forceinline__ Slot zero_slot() { return make_uint4(0u, 0u, 0u, 0u); }
@@ -274,6 +280,26 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 #pragma unroll
     for (int part = 0; part < HPARTS; ++part) stage_halo_part(0, 0, part);
     stage_w(0, 0);
+    // Norm-backward sums (see the epilogue): the wave's vectors of z.  The skewed-loop kernel has the registers to request
+    // them here, where the wait for the first halo covers their latency; the other variants load them in the epilogue.
+    struct alignas(16) Pack8 { T e[8]; };
+    constexpr bool kEarlyZ = PIPE;
+    Pack8 zr[NI / 2][NJ];
+    auto load_z = [&]() {
+#pragma unroll
+        for (int k2 = 0; k2 < NI / 2; ++k2) {
+            const int co = cb * BN + (wave / WPX_WAVES) * WCO + 32 * k2 + 8 * (lane >> 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int yy = y0 + (wave % WPX_WAVES) * NJ + j, xx = x0 + (lane & 15);
+                if (co < a.Cout && yy < a.H && xx < a.W)
+                    zr[k2][j] = *reinterpret_cast<const Pack8*>(reinterpret_cast<const T*>(a.nb_z) + (int64_t)a.vout.pixel(n, yy, xx) * a.nb_ldz + co);
+            }
+        }
+    };
+    if constexpr (kEarlyZ) {
+        if (a.nb_part) load_z();
+    }
     dma_wait_all();
     __syncthreads();
 
@@ -451,6 +477,72 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
     SEGK_PROBE_END();
     // ---- epilogue: bias, ReLU, mask, store 8 consecutive channels per lane (rows are in MFMA order) ----------
     static_assert(NI % 2 == 0, "channel tiles come in pairs");
+    if (a.nb_part) {
+        // The output is g = dL/d relu(norm(z)).  Store it, and reduce over the wave's pixels what the norm's backward
+        // needs: s1 = sum g*[pre > 0], s2 = sum g*[pre > 0]*zhat, with pre and zhat computed from z by the very
+        // expressions of the forward and of the dx pass, and g rounded to T as that pass will read it.
+        // All of the wave's z vectors are requested before the stores of g, so that their latency is paid once.
+        if constexpr (!kEarlyZ) load_z();
+#pragma unroll
+        for (int k2 = 0; k2 < NI / 2; ++k2) {
+            const int co = cb * BN + wco * WCO + 32 * k2 + 8 * g;
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
+                if (yy >= a.H || xx >= a.W) continue;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e]; v[4 + e] = acc[2 * k2 + 1][j][e]; }
+                Elem<T>::store8(reinterpret_cast<T*>(a.y) + (int64_t)a.vout.pixel(n, yy, xx) * a.ldy + co, v);
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < NI / 2; ++k2) {
+            const int co = cb * BN + wco * WCO + 32 * k2 + 8 * g;
+            if (co >= a.Cout) continue;
+            float mean[8], rstd[8], sc[8], sh[8], s1[8], s2[8];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 st = *reinterpret_cast<const float4*>(a.nb_stats + 2 * (co + 2 * q4));
+                mean[2 * q4] = st.x; rstd[2 * q4] = st.y; mean[2 * q4 + 1] = st.z; rstd[2 * q4 + 1] = st.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float ga = a.nb_gamma ? a.nb_gamma[co + r] : 1.f, be = a.nb_beta ? a.nb_beta[co + r] : 0.f;
+                sc[r] = rstd[r] * ga;
+                sh[r] = be - mean[r] * sc[r];
+                s1[r] = s2[r] = 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
+                if (yy >= a.H || xx >= a.W) continue;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    const float zz = Elem<T>::to_f(zr[k2][j].e[r]);
+                    const float pre = zz * sc[r] + sh[r];
+                    const float zh = (zz - mean[r]) * rstd[r];
+                    const float gv = r < 4 ? acc[2 * k2][j][r & 3] : acc[2 * k2 + 1][j][r & 3];
+                    const float gg = pre > 0.f ? Elem<T>::to_f(Elem<T>::from_f(gv)) : 0.f;
+                    s1[r] += gg;
+                    s2[r] += gg * zh;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+            if (l15 == 0) {
+                const int tile = (n * a.tiles_y + ty) * a.tiles_x + tx;
+                float* dst = a.nb_part + ((int64_t)(tile * WPX_WAVES + wpx) * 2) * a.Cout + co;
+                *reinterpret_cast<float4*>(dst) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(s1[4], s1[5], s1[6], s1[7]);
+                *reinterpret_cast<float4*>(dst + a.Cout) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+                *reinterpret_cast<float4*>(dst + a.Cout + 4) = make_float4(s2[4], s2[5], s2[6], s2[7]);
+            }
+        }
+        SEGK_PROBE_EXIT();
+        return;
+    }
     if (!a.stat_part) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -1263,10 +1355,13 @@ extern "C" int segk_conv_pack_batch(int dtype, const segk_pack_desc* descs_dev, 
     return SEGK_OK;
 }
 
-extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1, int64_t C1,
-                             int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout, const float* bias, void* y,
-                             int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask, int64_t ld_mask, int64_t mask_channels,
-                             float* stat_partials, int flags, int dev, void* stream) {
+// the norm-backward sums of segk_conv_dgrad_norm (all null for segk_conv_fwd)
+struct NormBwdSums { const void* z; int64_t ldz; const float* stats; const float* gamma; const float* beta; float* partials; };
+
+static int conv_fwd_impl(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1, int64_t C1,
+                         int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout, const float* bias, void* y,
+                         int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask, int64_t ld_mask, int64_t mask_channels,
+                         float* stat_partials, int flags, const NormBwdSums& nb, int dev, void* stream) {
     if (int rc = check_segments("conv_fwd", dtype, x0, ld0, C0, x1, ld1, C1)) return rc;
     SEGK_REQUIRE(!y1 || (split > 0 && split < Cout && split % 8 == 0 && ldy >= split && ldy1 >= Cout - split && aligned16(y1) &&
                          (ldy1 * esize(dtype)) % 16 == 0 && !mask),
@@ -1286,6 +1381,7 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     const int kr = krow(dtype);
     ConvArgs a;
     a.stat_part = stat_partials;
+    a.nb_z = (const char*)nb.z; a.nb_ldz = nb.ldz; a.nb_stats = nb.stats; a.nb_gamma = nb.gamma; a.nb_beta = nb.beta; a.nb_part = nb.partials;
     a.x0 = (const char*)x0; a.x1 = (const char*)x1; a.ld0 = ld0; a.ld1 = ld1;
     a.C0 = (int)C0; a.C1 = (int)C1;
     a.nch0 = (int)(round_up(C0, kr) / kr); a.nch = a.nch0 + (int)(round_up(C1, kr) / kr);
@@ -1304,6 +1400,25 @@ extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, i
     launch_fwd_any(dtype, taps, a, bn, st);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
+}
+
+extern "C" int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1, int64_t C1,
+                             int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout, const float* bias, void* y,
+                             int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask, int64_t ld_mask, int64_t mask_channels,
+                             float* stat_partials, int flags, int dev, void* stream) {
+    return conv_fwd_impl(dtype, taps, x0, ld0, C0, x1, ld1, C1, N, H, W, w_packed, Cout, bias, y, ldy, y1, ldy1, split, mask, ld_mask,
+                         mask_channels, stat_partials, flags, NormBwdSums{nullptr, 0, nullptr, nullptr, nullptr, nullptr}, dev, stream);
+}
+
+extern "C" int segk_conv_dgrad_norm(int dtype, int taps, const void* dy, int64_t ld_dy, int64_t C, int64_t N, int64_t H, int64_t W,
+                                    const void* w_packed, int64_t Cout, void* g, int64_t ldg, const void* z, int64_t ldz,
+                                    const float* stats, const float* gamma, const float* beta, float* partials, int dev, void* stream) {
+    SEGK_REQUIRE(dtype == SEGK_F32 || dtype == SEGK_BF16, SEGK_EINVAL, "conv_dgrad_norm: unknown dtype %d", dtype);
+    SEGK_REQUIRE(z && stats && partials && aligned16(z) && aligned16(stats) && aligned16(partials), SEGK_EINVAL,
+                 "conv_dgrad_norm: z, stats and partials must be non-null and 16-byte aligned");
+    SEGK_REQUIRE(ldz >= Cout && (ldz * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_dgrad_norm: z pixel stride misaligned or < Cout");
+    return conv_fwd_impl(dtype, taps, dy, ld_dy, C, nullptr, 0, 0, N, H, W, w_packed, Cout, nullptr, g, ldg, nullptr, 0, 0, nullptr, 0, 0,
+                         nullptr, 0, NormBwdSums{z, ldz, stats, gamma, beta, partials}, dev, stream);
 }
 
 // rows of per-wave output statistics segk_conv_fwd writes: (image, tile, pixel-wave); the pixel-wave count follows the

@@ -304,12 +304,12 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __r
 // pass 1b: red[(g*C+c)*2 + {0,1}] = {s1, s2}; dgamma/dbeta.  One workgroup per (channel, group).
 __global__ __launch_bounds__(kThreads) void norm_bwd_finalize_kernel(const float* __restrict__ ws, int bpg, int C,
                                                                      float* __restrict__ red, float* __restrict__ dgamma,
-                                                                     float* __restrict__ dbeta, int accumulate) {
+                                                                     float* __restrict__ dbeta, int accumulate, int64_t row_stride) {
     __shared__ double sm[4];
     const int g = blockIdx.y, c = blockIdx.x;
-    const int64_t base = (int64_t)g * bpg * 2 * C + c;
-    const double s1 = block_sum_partials(ws, base, 2 * (int64_t)C, bpg, sm);
-    const double s2 = block_sum_partials(ws, base + C, 2 * (int64_t)C, bpg, sm);
+    const int64_t base = (int64_t)g * bpg * row_stride + c;   // row_stride: floats between consecutive partial rows (2*C when dense)
+    const double s1 = block_sum_partials(ws, base, row_stride, bpg, sm);
+    const double s2 = block_sum_partials(ws, base + C, row_stride, bpg, sm);
     if (threadIdx.x != 0) return;
     red[((int64_t)g * C + c) * 2 + 0] = (float)s1;
     red[((int64_t)g * C + c) * 2 + 1] = (float)s2;
@@ -1330,7 +1330,7 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
                                                      (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, bpg, part));
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st,
-                       (const float*)part, bpg, (int)C, red, dgamma, dbeta, accumulate);
+                       (const float*)part, bpg, (int)C, red, dgamma, dbeta, accumulate, (int64_t)(2 * C));
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(M, rows, groups);
@@ -1344,6 +1344,54 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
         SEGK_REQUIRE(!frozen, SEGK_EINVAL, "norm_bwd: bias gradient with frozen statistics: use segk_colsum on dx");
         if (!accumulate) SEGK_HIP(hipMemsetAsync(dbias_out, 0, (size_t)C * sizeof(float), st));
     }
+    return SEGK_OK;
+}
+
+// Second half of segk_norm_bwd for a BatchNorm (one group) whose two sums were already reduced per wave by the
+// convolution that produced dy (segk_conv_dgrad_norm): column-sum the partial rows, finalize, write dx.
+extern "C" size_t segk_norm_bwd_finish_workspace(int64_t rows, int64_t C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return align_up(segk_norm_stats_finalize_workspace(1, rows, C), 256) + align_up((size_t)2 * C * sizeof(float), 256);
+}
+
+extern "C" int segk_norm_bwd_finish(int dtype, const float* partials, int64_t rows, const void* dy, int64_t ld_dy, const void* x,
+                                    int64_t ldx, int64_t M, int64_t C, const float* stats, const float* gamma, const float* beta,
+                                    int flags, void* dx, int64_t ld_dx, float* dgamma, float* dbeta, void* workspace,
+                                    size_t workspace_bytes, int dev, void* stream) {
+    SEGK_CHECK_ACT("norm_bwd_finish(dy)", dy, ld_dy, C, dtype);
+    SEGK_CHECK_ACT("norm_bwd_finish(x)", x, ldx, C, dtype);
+    SEGK_CHECK_ACT("norm_bwd_finish(dx)", dx, ld_dx, C, dtype);
+    if (int rc = check_norm_c("norm_bwd_finish", C)) return rc;
+    SEGK_REQUIRE(partials && aligned16(partials) && rows > 0 && rows < (1ll << 31) && stats && workspace && M > 0, SEGK_EINVAL,
+                 "norm_bwd_finish: bad arguments");
+    SEGK_REQUIRE(2 * C / 8 <= kThreads, SEGK_ESHAPE, "norm_bwd_finish: at most 1024 channels");
+    SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "norm_bwd_finish: dgamma/dbeta come in pairs");
+    SEGK_REQUIRE(!(flags & 4), SEGK_EINVAL, "norm_bwd_finish: frozen statistics need no sums: use segk_norm_bwd");
+    SEGK_REQUIRE(workspace_bytes >= segk_norm_bwd_finish_workspace(rows, C), SEGK_EWORKSPACE, "norm_bwd_finish: workspace too small");
+    SEGK_USE_DEVICE(dev);
+    hipStream_t st = (hipStream_t)stream;
+    const int relu = flags & 1, accumulate = (flags >> 1) & 1;
+    float* red = (float*)((char*)workspace + align_up(segk_norm_stats_finalize_workspace(1, rows, C), 256));
+    if (rows <= 128) {
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, 1), dim3(kThreads), 0, st, partials, (int)rows, (int)C, red, dgamma,
+                           dbeta, accumulate, (int64_t)(2 * C));
+    } else {
+        // coalesced column sum of the [rows][2C] matrix by many workgroups first (every second output row stays unused,
+        // hence the row stride of 4*C), then the per-channel finalize over the few rows that are left
+        const int bpg = stats_bpg(1, rows, 2 * C);
+        hipLaunchKernelGGL((stats_partial_kernel<float, 1>), dim3(bpg, 1), dim3(kThreads), 0, st, partials, 2 * C, rows, (int)(2 * C), bpg,
+                           (float*)workspace, (float*)nullptr);
+        SEGK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, 1), dim3(kThreads), 0, st, (const float*)workspace, bpg, (int)C, red,
+                           dgamma, dbeta, accumulate, (int64_t)(4 * C));
+    }
+    SEGK_LAUNCH_CHECK();
+    const int rws = kThreads / (int)(C / 8);
+    const int64_t gx = stream_blocks(M, rws, 1);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T>), dim3((unsigned)gx, 1), dim3(kThreads), 0, st,
+                                                     (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, 0,
+                                                     (const float*)red, (T*)dx, ld_dx, (flags >> 3) & 1));
+    SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
 
@@ -1392,7 +1440,7 @@ extern "C" int segk_norm_pool_bwd(int dtype, const void* dy, int64_t ld_dy, cons
                                                      beta, bpg, part));
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, 1), dim3(kThreads), 0, st, (const float*)part, bpg, (int)C,
-                       red, dgamma, dbeta, accumulate);
+                       red, dgamma, dbeta, accumulate, (int64_t)(2 * C));
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(Q, rows, 1);

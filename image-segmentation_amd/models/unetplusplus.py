@@ -38,7 +38,7 @@ class conv_block_nested(SegkBlock):
             y = rt.conv_first(image, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
         else:
             y = rt.conv(x, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
-        h = rt.bn_relu(y, prefix + "bn1")
+        h = rt.bn_relu(y, prefix + "bn1", one_reader=True)
         y = rt.conv(h, prefix + "conv2.weight", prefix + "conv2.bias", bias_grad_zero=zero, stats=True)
         return rt.bn_relu(y, prefix + "bn2", out=out, pool=pool)
 

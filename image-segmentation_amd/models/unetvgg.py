@@ -136,7 +136,7 @@ class _UNetVggBase(SegkNet):
                 if j == len(stage_widths) - 1:   # skip tensor (second slice of the concat buffer) + pool for the next stage
                     v, pooled = rt.bn_relu(y, bn_, out=Act(cat[k], widths[k][0], widths[k][1]), pool=True)
                 else:
-                    v = rt.bn_relu(y, bn_)
+                    v = rt.bn_relu(y, bn_, one_reader=True)        # read by the stage's next convolution only
                 idx += 3
             skips[k] = v
         d = self.center[1].emit(rt, "center.1.", pooled, out=Act(cat[5], 0, widths[5][0]))

@@ -42,6 +42,7 @@ _PROTOS = {
     "segk_conv_pack_batch": (I, [I, P, L, L, I, P]),
     "segk_conv_fwd": (I, [I, I, P, L, L, P, L, L, L, L, L, P, L, P, P, L, P, L, L, P, L, L, P, I, I, P]),
     "segk_conv_stat_rows": (L, [L, L, L, L]),
+    "segk_conv_dgrad_norm": (I, [I, I, P, L, L, L, L, L, P, L, P, L, P, L, P, P, P, P, I, P]),
     "segk_norm_stats_finalize_workspace": (Z, [L, L, L]),
     "segk_norm_stats_finalize": (I, [P, L, L, L, L, F, P, P, P, F, P, Z, I, P]),
     "segk_conv_wgrad_workspace": (Z, [I, I, L, L, L, L, L, L]),
@@ -77,6 +78,8 @@ _PROTOS = {
     "segk_norm_apply": (I, [I, P, L, L, L, L, P, P, P, I, P, L, I, P]),
     "segk_norm_eval_stats": (I, [P, P, L, F, P, I, P]),
     "segk_norm_bwd": (I, [I, P, L, P, L, L, L, L, P, P, P, I, P, L, P, P, P, P, Z, I, P]),
+    "segk_norm_bwd_finish_workspace": (Z, [L, L]),
+    "segk_norm_bwd_finish": (I, [I, P, L, P, L, P, L, L, L, P, P, P, I, P, L, P, P, P, Z, I, P]),
     "segk_norm_pool_apply": (I, [I, P, L, L, L, L, L, P, P, P, P, L, P, L, I, P]),
     "segk_norm_pool_bwd": (I, [I, P, L, P, L, P, L, L, L, L, L, P, P, P, I, P, L, P, P, P, Z, I, P]),
     "segk_maxpool2x2_fwd": (I, [I, P, L, L, L, L, L, P, L, I, P]),
@@ -94,6 +97,7 @@ _PROTOS = {
 
 _lib = None
 launches = 0   # number of C-ABI calls made by this process (tests assert the HIP path really ran)
+calls = {}     # the same per entry point
 
 
 class SegkError(RuntimeError):
@@ -130,6 +134,7 @@ def call(name, *args):
     h = lib()
     rc = getattr(h, name)(*args)
     launches += 1
+    calls[name] = calls.get(name, 0) + 1
     if rc != 0:
         msg = h.segk_last_error().decode(errors="replace")
         raise SegkError(f"{name} failed with {_ERR_NAMES.get(rc, rc)}: {msg}")

@@ -221,6 +221,29 @@ def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, a
     return out
 
 
+def conv_dgrad_norm(dy, w_packed, Cout, out, z, stats, gamma, beta, taps=9):
+    """out = data gradient (conv of dy with the packed data-gradient image) = gradient of relu(batchnorm(z)); returns the
+    per-wave partial rows of the two sums that batchnorm's backward needs (-> norm_bwd_finish)."""
+    assert out.C == Cout == z.C and (out.N, out.H, out.W) == (dy.N, dy.H, dy.W) == (z.N, z.H, z.W) and out.dtype == dy.dtype == z.dtype
+    dev, st = _env(dy.buf)
+    partials = conv_stat_partials(out)
+    with _Timed("conv_fwd", 2.0 * dy.P * Cout * dy.C * taps, "128-wide" if (Cout + 31) // 32 * 32 % 128 == 0 else "narrow"):
+        call("segk_conv_dgrad_norm", dt(dy.dtype), taps, dy.ptr, dy.ld, dy.C, dy.N, dy.H, dy.W, w_packed.data_ptr(), Cout, out.ptr,
+             out.ld, z.ptr, z.ld, stats.data_ptr(), _p(gamma), _p(beta), partials.data_ptr(), dev, st)
+    return partials
+
+
+def norm_bwd_finish(partials, dy, x, stats, gamma, beta, relu, dx, dgamma=None, dbeta=None, accumulate=False, add_dx=False):
+    """norm_bwd for a BatchNorm whose sums were produced by conv_dgrad_norm."""
+    rows = partials.shape[0]
+    dev, st = _env(x.buf)
+    ws = workspace(query("segk_norm_bwd_finish_workspace", rows, x.C), x.device)
+    flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (8 if add_dx else 0)
+    call("segk_norm_bwd_finish", dt(x.dtype), partials.data_ptr(), rows, dy.ptr, dy.ld, x.ptr, x.ld, x.P, x.C, stats.data_ptr(),
+         _p(gamma), _p(beta), flags, dx.ptr, dx.ld, _p(dgamma), _p(dbeta), ws.data_ptr(), ws.numel(), dev, st)
+    return dx
+
+
 def conv_wgrad(x, dy, dw, taps=9, cin_real=None, accumulate=False):
     """dw (fp32 [Cout, cin_real, taps]) = sum_pixels dy (x) shifted x."""
     a, b = _segs(x)

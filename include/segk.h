@@ -189,6 +189,19 @@ int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, 
  * y; segk_norm_stats_finalize turns them into the stats vector.  Needs one destination, no mask, no accumulation.  */
 int64_t segk_conv_stat_rows(int64_t N, int64_t H, int64_t W, int64_t Cout);
 
+/* Data gradient of a convolution whose input was h = relu(batchnorm(z)) and had no other reader
+ * (conv -> BatchNorm -> ReLU -> conv: models/unetvgg.py:72-76 through the VGG stages, models/unetplusplus.py:20-25):
+ * g = segk_conv_fwd(dy, data-gradient image) [N,H,W,Cout], and in the same epilogue the two sums the backward of that
+ * BatchNorm needs -- partials[row][0][c] = sum g*[norm(z)>0], partials[row][1][c] = sum g*[norm(z)>0]*zhat over the
+ * pixels of (image, tile, pixel-wave) `row`, segk_conv_stat_rows(N,H,W,Cout) rows -- so that segk_norm_bwd_finish
+ * needs no reduction pass over g and z.  z: the norm's input (same dtype, pixel stride ldz), stats {mean, 1/std}
+ * interleaved as segk_norm_stats writes them, gamma/beta may be NULL.
+ * replaces: half of the first pass of autograd's batch_norm backward, fused into the convolution backward in front of it. */
+int segk_conv_dgrad_norm(int dtype, int taps, const void* dy, int64_t ld_dy, int64_t C, int64_t N, int64_t H, int64_t W,
+                         const void* w_packed, int64_t Cout, void* g, int64_t ldg, const void* z, int64_t ldz,
+                         const float* stats, const float* gamma, const float* beta, float* partials, int dev,
+                         void* stream);
+
 /* dw[co,ci,ky,kx] (fp32 OIHW, [Cout, cin_real, taps]) = sum_{n,y,x} dy[n,y,x,co] * x[n,y+ky-1,x+kx-1,ci]
  * replaces: the weight-gradient half of Conv2d's backward.  The pixels are split over workgroups
  * whose partial slabs are summed in fixed order (deterministic).  flags bit1: dw += result.
@@ -344,6 +357,15 @@ int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const void* x, int64
                   int64_t M, int64_t C, const float* stats, const float* gamma, const float* beta, int flags,
                   void* dx, int64_t ld_dx, float* dgamma, float* dbeta, float* dbias_out, void* workspace,
                   size_t workspace_bytes, int dev, void* stream);
+
+/* segk_norm_bwd for one group (BatchNorm, batch statistics) whose two sums arrive as the partial rows of
+ * segk_conv_dgrad_norm ([rows][2][C]): fixed-order reduction of the rows, dgamma/dbeta, then the dx pass.
+ * flags as segk_norm_bwd (bit2 not allowed).                                                        */
+size_t segk_norm_bwd_finish_workspace(int64_t rows, int64_t C);
+int segk_norm_bwd_finish(int dtype, const float* partials, int64_t rows, const void* dy, int64_t ld_dy, const void* x,
+                         int64_t ldx, int64_t M, int64_t C, const float* stats, const float* gamma, const float* beta,
+                         int flags, void* dx, int64_t ld_dx, float* dgamma, float* dbeta, void* workspace,
+                         size_t workspace_bytes, int dev, void* stream);
 
 /* BatchNorm (batch or running statistics in `stats`) + ReLU + the 2x2/stride-2 max pool behind it, one pass:
  * y = relu(norm(x)) [N,H,W,C] and pool = maxpool2x2(y) [N,H/2,W/2,C].

@@ -41,7 +41,14 @@ for name, H, Cin, Cout in LAYERS:
         for _ in range(2): f()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        # SUSTAIN=ms: keep the kernel running that long before and during the measurement, so the figure is taken at the
+        # clock the chip holds under load and not in the boost window after an idle phase
         reps = 5
+        sustain = float(os.environ.get("SUSTAIN", 0))
+        if sustain:
+            e0.record(); f(); e1.record(); torch.cuda.synchronize()
+            reps = max(5, int(sustain / max(e0.elapsed_time(e1), 1e-3)))
+            for _ in range(reps): f()
         e0.record()
         for _ in range(reps): f()
         e1.record(); torch.cuda.synchronize()

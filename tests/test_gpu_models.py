@@ -305,6 +305,25 @@ def test_weight_gradients_on_side_stream(monkeypatch):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("name", ["unetvgg_c4", "nestedunet_c4"])
+def test_norm_backward_sums_from_the_data_gradient(monkeypatch, name):
+    """Opt-in SEGK_NORM_FUSE=1: the data gradient of the convolution behind a BatchNorm + ReLU also reduces the two sums
+    of that norm's backward.  Same arithmetic per element, sums added in another order: gradients agree to fp32 rounding."""
+    from segk import engine, _lib
+    grads, fused = [], []
+    for flag in (False, True):
+        monkeypatch.setattr(engine, "_NORM_FUSE", flag)
+        before = _lib.calls.get("segk_conv_dgrad_norm", 0)
+        model, logits, loss = run_step(name, torch.float32)
+        fused.append(_lib.calls.get("segk_conv_dgrad_norm", 0) - before)
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters()})
+    assert fused[0] == 0 and fused[1] >= 8, f"fused data gradients launched: {fused}"
+    for k, a in grads[0].items():
+        b = grads[1][k]
+        scale = float(a.norm())
+        assert float((a - b).norm()) <= 2e-5 * scale + 1e-9, k
+
+
 def test_unetsimple_reference_width_vs_oracle():
     """UNetSimple as the reference trains it (roi_train/train_roi.py:39,52: one input channel, channelscale 128, up to
     1024-wide layers and a 2048-channel concat): fp32 logits, loss and the last layers' gradients against the oracle on

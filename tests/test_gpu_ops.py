@@ -500,6 +500,38 @@ def test_conv_epilogue_statistics(dtype, case):
             report("running_var", rv1.cpu(), rv0.cpu(), rtol=1e-5, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64), (3, 20, 24, 96, 128), (2, 12, 40, 128, 32), (1, 9, 17, 32, 64), (2, 24, 24, 64, 96),
+                                  (20, 64, 64, 64, 64)], ids=lambda c: "x".join(map(str, c)))
+def test_conv_dgrad_with_norm_backward_sums(dtype, case):
+    """Data gradient whose epilogue also reduces the two sums of the BatchNorm backward in front of it
+    (conv -> BatchNorm -> ReLU -> conv, models/unetvgg.py:72-76; models/unetplusplus.py:20-25): the stored gradient is
+    bitwise the plain data gradient, and dx / dgamma / dbeta equal those of the two-pass norm backward on it (every
+    channel-block width, partial tiles, enough rows for the two-level reduction)."""
+    from segk import ops
+    N, H, W, Cup, C = case                                     # dy has Cup channels, the norm C
+    dy = to_act(rnd((N, Cup, H, W), dtype, 1), dtype)
+    w = rnd((Cup, C, 3, 3), dtype, 2, scale=(2.0 / (9 * C)) ** 0.5)
+    _, wb = ops.conv_pack(w.cuda(), dtype, want_fwd=False)
+    z = to_act(rnd((N, C, H, W), dtype, 3), dtype)
+    gamma, beta = (rnd((C,), torch.float32, 4) * 0.3 + 1).cuda(), (rnd((C,), torch.float32, 5) * 0.3).cuda()
+    stats = torch.empty(2 * C, device="cuda")
+    ops.norm_stats(z, 1, 1e-5, stats)
+    g0, g1 = ops.Act.empty(N, H, W, C, dtype, "cuda"), ops.Act(torch.zeros(N, H, W, C + 8, dtype=dtype, device="cuda"), 8, C)
+    dx0, dx1 = ops.Act.empty(N, H, W, C, dtype, "cuda"), ops.Act.empty(N, H, W, C, dtype, "cuda")
+    dg0, db0, dg1, db1 = (torch.empty(C, device="cuda") for _ in range(4))
+    ops.conv_fwd(dy, wb, C, g0)
+    ops.norm_bwd(g0, z, 1, stats, gamma, beta, True, dx0, dgamma=dg0, dbeta=db0)
+    part = ops.conv_dgrad_norm(dy, wb, C, g1, z, stats, gamma, beta)
+    assert torch.isfinite(part).all()
+    assert torch.equal(g1.nchw(), g0.nchw())
+    ops.norm_bwd_finish(part, g1, z, stats, gamma, beta, True, dx1, dgamma=dg1, dbeta=db1)
+    tol = 2e-5 if dtype == torch.float32 else 1e-2             # bf16: dx is rounded after sums that differ in the last bits
+    report("dgamma", dg1.cpu(), dg0.cpu(), rtol=2e-5, atol=2e-5 * float(dg0.abs().max()))
+    report("dbeta", db1.cpu(), db0.cpu(), rtol=2e-5, atol=2e-5 * float(db0.abs().max()))
+    report("dx", dx1.nchw().float().cpu(), dx0.nchw().float().cpu(), rtol=tol, atol=tol * float(dx0.nchw().float().abs().max()))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_strided_2x2_convolution(dtype):
     """Conv2d(kernel_size=2, stride=2) (models/unetvgg.py:305) = 2x2 block gather + 1x1 convolution; forward, weight,
