@@ -25,6 +25,7 @@ which = sys.argv[1:] or ["fwd", "dgrad", "wgrad"]
 tot = {k: 0.0 for k in which}
 totf = 0.0
 for name, H, Cin, Cout in LAYERS:
+    torch.manual_seed(0)
     x = Act(torch.randn(N, H, H, Cin, device="cuda").to(dtype))
     dy = Act(torch.randn(N, H, H, Cout, device="cuda").to(dtype))
     w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
@@ -56,5 +57,8 @@ for name, H, Cin, Cout in LAYERS:
         tot[k] += ms
         line += f" {k} {ms*1e3:7.1f} us {fl/ms/1e9:6.0f} TF |"
     totf += fl
+    if os.environ.get("CHECK"):      # checksums of the results (compare two builds / modes on identical inputs)
+        torch.cuda.synchronize()
+        line += f" sum|y| {float(y.buf.float().abs().sum()):.6e} sum|dx| {float(dx.buf.float().abs().sum()):.6e}"
     print(line, flush=True)
 print("TOTAL", {k: f"{v:.2f} ms {totf/v/1e9:.0f} TF" for k, v in tot.items()})
