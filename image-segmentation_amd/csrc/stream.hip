@@ -612,6 +612,12 @@ __global__ __launch_bounds__(kThreads) void maxpool_bwd_kernel(const T* __restri
 // by the block's own L1 instead of being fetched once per XCD (consecutive blocks run on different XCDs, whose L2s
 // do not share lines).
 struct PatchItem { int64_t n; int h, w, v; bool ok; };
+// Blocks are dealt to the 8 XCDs round-robin and every XCD has its own L2: renumber so that each XCD walks one contiguous
+// eighth of the block list, and patches whose neighbourhoods overlap meet in one L2.
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned G) {
+    const unsigned base = G >> 3, rem = G & 7, x = b & 7;
+    return x * base + (x < rem ? x : rem) + (b >> 3);
+}
 __host__ __device__ inline int patch_cg(int cv) { return cv % 8 == 0 ? 8 : (cv % 4 == 0 ? 4 : (cv % 2 == 0 ? 2 : 1)); }
 static inline int64_t patch_blocks(int64_t N, int64_t H, int64_t W, int64_t C) {
     const int cv = (int)(C / 8), cg = patch_cg(cv), ty = kThreads / (8 * cg);
@@ -837,24 +843,45 @@ __global__ __launch_bounds__(kThreads) void resize_bwd_kernel(const T* __restric
 // weight on input 0, and past the last row the clamped neighbour is the row itself.  One thread owns one INPUT
 // pixel (8 channels).
 //
-// forward: 3x3 input neighbourhood -> the 2x2 output block, same expression per output as the generic kernel
+// forward: 3x3 input neighbourhood -> the 2x2 output block, same expression per output as the generic kernel.  The block
+// stages the (TY+2) x 10 input pixels of its TY x 8 patch in LDS (rows and columns clamped at the image border, as the
+// interpolation clamps them), so every input vector is fetched once per block and the nine taps come from LDS.
+constexpr int kUpInSlots = 480;      // max over channel groups cg of (TY + 2) * 10 * cg with TY = 256 / (8*cg): cg = 8
 template <typename T>
 __global__ __launch_bounds__(kThreads) void upsample_fwd_half_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
                                                                      const float* __restrict__ stats, int relu,
                                                                      T* __restrict__ y, int64_t ldy) {
+    struct alignas(16) Pack8 { T e[8]; };
+    __shared__ Pack8 tile[kUpInSlots];
     const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
-    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, H, W, cv);
+    const int cg = patch_cg(cv), ty = kThreads / (8 * cg);
+    const PatchItem it = patch_item(xcd_contiguous_block(blockIdx.x, gridDim.x), threadIdx.x, H, W, cv);
+    const int lh = threadIdx.x / (cg * 8), lw = (threadIdx.x / cg) % 8, lv = threadIdx.x % cg;
+    const int h0 = it.h - lh, w0 = it.w - lw, v0 = it.v - lv;
+    const int64_t n = it.n;
+    constexpr int RW = 10;
+    const T* b = x + n * H * W * ldx;
+    const int slots = (ty + 2) * RW * cg;
+    for (int s = threadIdx.x; s < slots; s += kThreads) {
+        const int vv = s % cg, px = s / cg;
+        const int ry = px / RW, rx = px - ry * RW;
+        int iy = h0 - 1 + ry, ix = w0 - 1 + rx;
+        iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+        tile[s] = *reinterpret_cast<const Pack8*>(b + ((int64_t)iy * W + ix) * ldx + (v0 + vv) * 8);
+    }
+    __syncthreads();
     if (!it.ok) return;
     const int h = it.h, w = it.w, v = it.v;
-    const int64_t n = it.n;
-    const int hs[3] = {h > 0 ? h - 1 : 0, h, h < H - 1 ? h + 1 : h};
-    const int ws[3] = {w > 0 ? w - 1 : 0, w, w < W - 1 ? w + 1 : w};
-    const T* b = x + n * H * W * ldx + v * 8;
     float a[3][3][8];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) Elem<T>::load8(b + ((int64_t)hs[r] * W + ws[c]) * ldx, a[r][c]);
+        for (int c = 0; c < 3; ++c) {
+            const Pack8 t = tile[((lh + r) * RW + lw + c) * cg + lv];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[r][c][j] = Elem<T>::to_f(t.e[j]);
+        }
     float mean[8], rstd[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -880,20 +907,48 @@ __global__ __launch_bounds__(kThreads) void upsample_fwd_half_kernel(const T* __
         }
 }
 
-// backward: the 4x4 output neighbourhood [2h-1, 2h+2] x [2w-1, 2w+2] with separable weights
+// backward: the 4x4 output neighbourhood [2h-1, 2h+2] x [2w-1, 2w+2] with separable weights.  Neighbouring input pixels
+// share three quarters of that neighbourhood, so the block first stages the (2*TY+2) x 18 output pixels its TY x 8 patch needs
+// in LDS -- every gradient vector is fetched once per block (already masked by the ReLU when asked) -- and each thread
+// then gathers its sixteen taps from there.  Positions outside the image hold zeros; their weights are zero as well.
+constexpr int kUpTileSlots = 1440;   // max over channel groups cg of (2*TY + 2) * 18 * cg with TY = 256 / (8*cg): cg = 8
 template <typename T>
 __global__ __launch_bounds__(kThreads) void upsample_bwd_half_kernel(const T* __restrict__ dy, int64_t ld_dy,
                                                                      const T* __restrict__ y, int64_t ldy, int H, int W, int C,
                                                                      int relu, T* __restrict__ dx, int64_t ld_dx) {
+    struct alignas(16) Pack8 { T e[8]; };
+    __shared__ Pack8 tile[kUpTileSlots];
     const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
-    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, H, W, cv);
+    const int cg = patch_cg(cv), ty = kThreads / (8 * cg);
+    const PatchItem it = patch_item(xcd_contiguous_block(blockIdx.x, gridDim.x), threadIdx.x, H, W, cv);
+    const int lh = threadIdx.x / (cg * 8), lw = (threadIdx.x / cg) % 8, lv = threadIdx.x % cg;
+    const int h0 = it.h - lh, w0 = it.w - lw, v0 = it.v - lv;      // the patch's first pixel and channel vector
+    const int64_t n = it.n;
+    constexpr int RW = 18;
+    const int slots = (2 * ty + 2) * RW * cg;
+    for (int s = threadIdx.x; s < slots; s += kThreads) {
+        const int vv = s % cg, px = s / cg;
+        const int ry = px / RW, rx = px - ry * RW;
+        const int oy = 2 * h0 - 1 + ry, ox = 2 * w0 - 1 + rx;
+        Pack8 val;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) val.e[j] = Elem<T>::from_f(0.f);
+        if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+            const int64_t op = (n * Ho + oy) * Wo + ox;
+            val = *reinterpret_cast<const Pack8*>(dy + op * ld_dy + (v0 + vv) * 8);
+            if (relu) {
+                const Pack8 f = *reinterpret_cast<const Pack8*>(y + op * ldy + (v0 + vv) * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val.e[j] = Elem<T>::to_f(f.e[j]) > 0.f ? val.e[j] : Elem<T>::from_f(0.f);
+            }
+        }
+        tile[s] = val;
+    }
+    __syncthreads();
     if (!it.ok) return;
     const int h = it.h, w = it.w, v = it.v;
-    const int64_t n = it.n;
     const float wy[4] = {h > 0 ? 0.25f : 0.f, h > 0 ? 0.75f : 1.f, h < H - 1 ? 0.75f : 1.f, h < H - 1 ? 0.25f : 0.f};
     const float wx[4] = {w > 0 ? 0.25f : 0.f, w > 0 ? 0.75f : 1.f, w < W - 1 ? 0.75f : 1.f, w < W - 1 ? 0.25f : 0.f};
-    const int oy[4] = {h > 0 ? 2 * h - 1 : 0, 2 * h, 2 * h + 1, h < H - 1 ? 2 * h + 2 : 2 * h + 1};
-    const int ox[4] = {w > 0 ? 2 * w - 1 : 0, 2 * w, 2 * w + 1, w < W - 1 ? 2 * w + 2 : 2 * w + 1};
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
@@ -905,17 +960,9 @@ __global__ __launch_bounds__(kThreads) void upsample_bwd_half_kernel(const T* __
         for (int j = 0; j < 8; ++j) row[j] = 0.f;
 #pragma unroll
         for (int kx = 0; kx < 4; ++kx) {
-            const int64_t op = (n * Ho + oy[ky]) * Wo + ox[kx];
-            float d[8];
-            Elem<T>::load8(dy + op * ld_dy + v * 8, d);
-            if (relu) {
-                float f[8];
-                Elem<T>::load8(y + op * ldy + v * 8, f);
+            const Pack8 d = tile[((2 * lh + ky) * RW + 2 * lw + kx) * cg + lv];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = f[j] > 0.f ? d[j] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) row[j] += wx[kx] * d[j];
+            for (int j = 0; j < 8; ++j) row[j] += wx[kx] * Elem<T>::to_f(d.e[j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += wy[ky] * row[j];
