@@ -659,34 +659,6 @@ __device__ __forceinline__ Lerp lerp_taps(int o, int in, bool align) {
     return l;
 }
 
-template <typename T>
-__global__ __launch_bounds__(kThreads) void upsample_fwd_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
-                                                                const float* __restrict__ stats, int relu, int align,
-                                                                T* __restrict__ y, int64_t ldy) {
-    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
-    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, Ho, Wo, cv);   // one OUTPUT pixel (8 channels) per thread
-    if (!it.ok) return;
-    const int oy = it.h, ox = it.w, v = it.v;
-    const int64_t n = it.n;
-    const Lerp ly = lerp_taps(oy, H, align != 0), lx = lerp_taps(ox, W, align != 0);
-    const T* b = x + n * H * W * ldx + v * 8;
-    float a00[8], a01[8], a10[8], a11[8], o[8];
-    Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i0) * ldx, a00);
-    Elem<T>::load8(b + ((int64_t)ly.i0 * W + lx.i1) * ldx, a01);
-    Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i0) * ldx, a10);
-    Elem<T>::load8(b + ((int64_t)ly.i1 * W + lx.i1) * ldx, a11);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        float val = ly.w0 * (lx.w0 * a00[j] + lx.w1 * a01[j]) + ly.w1 * (lx.w0 * a10[j] + lx.w1 * a11[j]);
-        if (stats) {
-            const int c = v * 8 + j;
-            val = (val - stats[(n * C + c) * 2]) * stats[(n * C + c) * 2 + 1];
-        }
-        o[j] = relu ? fmaxf(val, 0.f) : val;
-    }
-    Elem<T>::store8(y + ((n * Ho + oy) * Wo + ox) * ldy + v * 8, o);
-}
-
 // adjoint of the interpolation (gather form): every input pixel collects from the output pixels whose
 // taps include it.  For x2 up-sampling those lie in [2h-3, 2h+3] for either corner convention.
 template <typename T>
@@ -838,15 +810,80 @@ __global__ __launch_bounds__(kThreads) void resize_bwd_kernel(const T* __restric
     Elem<T>::store8(dst, acc);
 }
 
-// Fast paths for align_corners=False (the decoder blocks): with scale 2 the taps are fixed.  Output rows 2h and
-// 2h+1 read input rows (h-1, h) and (h, h+1) with weights (0.25, 0.75) and (0.75, 0.25); output 0 puts all its
-// weight on input 0, and past the last row the clamped neighbour is the row itself.  One thread owns one INPUT
-// pixel (8 channels).
+// Block-wise x2 kernels.  One thread owns one INPUT pixel (8 channels).
 //
-// forward: 3x3 input neighbourhood -> the 2x2 output block, same expression per output as the generic kernel.  The block
-// stages the (TY+2) x 10 input pixels of its TY x 8 patch in LDS (rows and columns clamped at the image border, as the
-// interpolation clamps them), so every input vector is fetched once per block and the nine taps come from LDS.
+// forward (either corner convention): the four outputs (2h + dy, 2w + dx) of input pixel (h, w) interpolate inside its 3x3
+// neighbourhood -- align_corners=False: rows (h-1, h) and (h, h+1) with weights (0.25, 0.75) and (0.75, 0.25);
+// align_corners=True: source coordinate o*(H-1)/(2H-1), which lies in (h-1, h] for o = 2h and in (h, h+1) for o = 2h+1.
+// The block stages the (TY+2) x 10 input pixels of its TY x 8 patch in LDS (rows and columns clamped at the image border,
+// as the interpolation clamps them), so every input vector is fetched once per block; the taps of every output are
+// looked up there by the indices ATen's formula gives, and combined in ATen's order.  Four stores per thread keep
+// four times the bytes of a one-output-per-thread kernel in flight.
 constexpr int kUpInSlots = 480;      // max over channel groups cg of (TY + 2) * 10 * cg with TY = 256 / (8*cg): cg = 8
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_fwd_block_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
+                                                                      const float* __restrict__ stats, int relu, int align,
+                                                                      T* __restrict__ y, int64_t ldy) {
+    struct alignas(16) Pack8 { T e[8]; };
+    __shared__ Pack8 tile[kUpInSlots];
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const int cg = patch_cg(cv), ty = kThreads / (8 * cg);
+    const PatchItem it = patch_item(xcd_contiguous_block(blockIdx.x, gridDim.x), threadIdx.x, H, W, cv);
+    const int lh = threadIdx.x / (cg * 8), lw = (threadIdx.x / cg) % 8, lv = threadIdx.x % cg;
+    const int h0 = it.h - lh, w0 = it.w - lw, v0 = it.v - lv;
+    const int64_t n = it.n;
+    constexpr int RW = 10;
+    const T* b = x + n * H * W * ldx;
+    const int slots = (ty + 2) * RW * cg;
+    for (int s = threadIdx.x; s < slots; s += kThreads) {
+        const int vv = s % cg, px = s / cg;
+        const int ry = px / RW, rx = px - ry * RW;
+        int iy = h0 - 1 + ry, ix = w0 - 1 + rx;
+        iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix);
+        tile[s] = *reinterpret_cast<const Pack8*>(b + ((int64_t)iy * W + ix) * ldx + (v0 + vv) * 8);
+    }
+    __syncthreads();
+    if (!it.ok) return;
+    const int h = it.h, w = it.w, v = it.v;
+    float mean[8], rstd[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = v * 8 + j;
+        mean[j] = stats ? stats[(n * C + c) * 2] : 0.f;
+        rstd[j] = stats ? stats[(n * C + c) * 2 + 1] : 1.f;
+    }
+    Lerp lys[2], lxs[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) { lys[d] = lerp_taps(2 * h + d, H, align != 0); lxs[d] = lerp_taps(2 * w + d, W, align != 0); }
+    auto tap = [&](int iy, int ix, float (&a)[8]) {
+        const Pack8 t = tile[((iy - h0 + 1) * RW + ix - w0 + 1) * cg + lv];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = Elem<T>::to_f(t.e[j]);
+    };
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const Lerp ly = lys[dy], lx = lxs[dx];
+            float a00[8], a01[8], a10[8], a11[8], o[8];
+            tap(ly.i0, lx.i0, a00);
+            tap(ly.i0, lx.i1, a01);
+            tap(ly.i1, lx.i0, a10);
+            tap(ly.i1, lx.i1, a11);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float val = ly.w0 * (lx.w0 * a00[j] + lx.w1 * a01[j]) + ly.w1 * (lx.w0 * a10[j] + lx.w1 * a11[j]);
+                if (stats) val = (val - mean[j]) * rstd[j];
+                o[j] = relu ? fmaxf(val, 0.f) : val;
+            }
+            Elem<T>::store8(y + ((n * Ho + 2 * h + dy) * Wo + 2 * w + dx) * ldy + v * 8, o);
+        }
+}
+
+// forward, align_corners=False: the same staging with the taps and weights fixed at compile time (output rows 2h and 2h+1
+// read input rows (h-1, h) and (h, h+1) with weights (0.25, 0.75) and (0.75, 0.25); output 0 puts all its weight on input 0,
+// and past the last row the clamped neighbour is the row itself).
 template <typename T>
 __global__ __launch_bounds__(kThreads) void upsample_fwd_half_kernel(const T* __restrict__ x, int64_t ldx, int H, int W, int C,
                                                                      const float* __restrict__ stats, int relu,
@@ -907,7 +944,9 @@ __global__ __launch_bounds__(kThreads) void upsample_fwd_half_kernel(const T* __
         }
 }
 
-// backward: the 4x4 output neighbourhood [2h-1, 2h+2] x [2w-1, 2w+2] with separable weights.  Neighbouring input pixels
+// backward, align_corners=False (the decoder blocks; fixed taps: output rows 2h and 2h+1 read input rows (h-1, h) and (h, h+1) with
+// weights (0.25, 0.75) and (0.75, 0.25), clamped at the border): the 4x4 output neighbourhood [2h-1, 2h+2] x [2w-1, 2w+2] with
+// separable weights.  Neighbouring input pixels
 // share three quarters of that neighbourhood, so the block first stages the (2*TY+2) x 18 output pixels its TY x 8 patch needs
 // in LDS -- every gradient vector is fetched once per block (already masked by the ReLU when asked) -- and each thread
 // then gathers its sixteen taps from there.  Positions outside the image hold zeros; their weights are zero as well.
@@ -1045,23 +1084,28 @@ __global__ __launch_bounds__(kThreads) void relu_bwd_kernel(const T* __restrict_
 // ------------------------------------------------------------------------------ 1x1 head
 constexpr int kHeadMaxOut = 8;
 
+// One thread per pixel computes all Cout dot products and writes them class-plane by class-plane (consecutive lanes =
+// consecutive pixels: coalesced fp32 stores).  The pixel rows a block works on are first copied to LDS with coalesced
+// 16-byte loads (TP pixels per round; rows padded by 16 bytes so that one-row-per-lane 16-byte reads are conflict-free):
+// a thread walking its own pixel row in global memory would touch a new 128-byte line per lane and load.
+// TP == 0: rows too long for LDS, threads read global memory directly.
 template <typename T>
 __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const T* __restrict__ x, int64_t ld, int Cin, int64_t N,
                                                             int64_t HW, const float* __restrict__ w,
                                                             const float* __restrict__ bias, int Cout,
-                                                            float* __restrict__ logits) {
-    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [Cout][Cin] + [Cout]
+                                                            float* __restrict__ logits, int TP) {
+    extern __shared__ __attribute__((aligned(16))) float wsm[];   // [Cout][Cin] + [Cout], then the pixel rows
+    struct alignas(16) Pack8 { T e[8]; };
     for (int i = threadIdx.x; i < Cout * Cin; i += kThreads) wsm[i] = w[i];
     for (int i = threadIdx.x; i < Cout; i += kThreads) wsm[Cout * Cin + i] = bias ? bias[i] : 0.f;
-    __syncthreads();
     const int64_t P = N * HW;
-    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < P; p += (int64_t)gridDim.x * kThreads) {
+    auto finish = [&](int64_t p, const T* row) {
         float acc[kHeadMaxOut];
 #pragma unroll
         for (int c = 0; c < kHeadMaxOut; ++c) acc[c] = c < Cout ? wsm[Cout * Cin + c] : 0.f;
         for (int k = 0; k < Cin; k += 8) {
             float a[8];
-            Elem<T>::load8(x + p * ld + k, a);
+            Elem<T>::load8(row + k, a);
 #pragma unroll
             for (int c = 0; c < kHeadMaxOut; ++c)
                 if (c < Cout) {
@@ -1073,6 +1117,22 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(const T* __restrict_
 #pragma unroll
         for (int c = 0; c < kHeadMaxOut; ++c)
             if (c < Cout) logits[(n * Cout + c) * HW + hw] = acc[c];
+    };
+    if (TP == 0) {
+        __syncthreads();
+        for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < P; p += (int64_t)gridDim.x * kThreads) finish(p, x + p * ld);
+        return;
+    }
+    const int cv = Cin / 8, rowe = Cin + 16 / (int)sizeof(T);      // padded row length in elements
+    T* rows = reinterpret_cast<T*>(wsm + ((Cout * Cin + Cout + 3) & ~3));
+    for (int64_t p0 = (int64_t)blockIdx.x * TP; p0 < P; p0 += (int64_t)gridDim.x * TP) {
+        __syncthreads();                                            // weights written / previous rows consumed
+        for (int s = threadIdx.x; s < TP * cv; s += kThreads) {
+            const int px = s / cv, v = s - px * cv;
+            if (p0 + px < P) *reinterpret_cast<Pack8*>(rows + px * rowe + v * 8) = *reinterpret_cast<const Pack8*>(x + (p0 + px) * ld + v * 8);
+        }
+        __syncthreads();
+        if (threadIdx.x < TP && p0 + threadIdx.x < P) finish(p0 + threadIdx.x, rows + threadIdx.x * rowe);
     }
 }
 
@@ -1539,9 +1599,9 @@ extern "C" int segk_upsample2x_fwd(int dtype, const void* x, int64_t ldx, int64_
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_kernel<T>), dim3((unsigned)patch_blocks(N, 2 * H, 2 * W, C)), dim3(kThreads), 0,
-                                                     (hipStream_t)stream, (const T*)x, ldx, (int)H, (int)W, (int)C, stats, flags & 1,
-                                                     (flags >> 2) & 1, (T*)y, ldy));
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_fwd_block_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads),
+                                                     0, (hipStream_t)stream, (const T*)x, ldx, (int)H, (int)W, (int)C, stats,
+                                                     flags & 1, 1, (T*)y, ldy));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1650,9 +1710,17 @@ extern "C" int segk_head1x1_fwd(int dtype, const void* x, int64_t ld, int64_t Ci
     SEGK_REQUIRE(w && logits && N > 0 && HW > 0, SEGK_EINVAL, "head1x1_fwd: bad arguments");
     SEGK_REQUIRE(Cout >= 1 && Cout <= kHeadMaxOut && Cin <= 1024, SEGK_ESHAPE, "head1x1_fwd: Cout must be 1..8 (got %lld)", (long long)Cout);
     SEGK_USE_DEVICE(dev);
-    const size_t smem = (size_t)(Cout * Cin + Cout) * sizeof(float);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid_for(N * HW, 4096)), dim3(kThreads), smem,
-                                                     (hipStream_t)stream, (const T*)x, ld, (int)Cin, N, HW, w, bias, (int)Cout, logits));
+    // pixel rows staged in LDS, TP per round: as many as fit next to the weights in 48 KB (none: direct reads)
+    const size_t wbytes = (size_t)((Cout * Cin + Cout + 3) & ~3) * sizeof(float);
+    const size_t rowb = (size_t)Cin * esize(dtype) + 16;
+    int tp = kThreads;
+    while (tp >= 64 && wbytes + tp * rowb > 48 * 1024) tp /= 2;
+    if (tp < 64) tp = 0;
+    const size_t smem = wbytes + (size_t)tp * rowb;
+    const int64_t units = tp ? (N * HW + tp - 1) / tp : (N * HW + kThreads - 1) / kThreads;
+    const unsigned grid = (unsigned)(units < 4096 ? (units < 1 ? 1 : units) : 4096);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((head_fwd_kernel<T>), dim3(grid), dim3(kThreads), smem,
+                                                     (hipStream_t)stream, (const T*)x, ld, (int)Cin, N, HW, w, bias, (int)Cout, logits, tp));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

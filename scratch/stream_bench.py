@@ -7,8 +7,8 @@ from segk.ops import Act
 N = 32
 dt = torch.bfloat16
 
-def timeit(f, reps=5):
-    for _ in range(2): f()
+def timeit(f, reps=int(os.environ.get('REPS', 5))):
+    for _ in range(max(2, reps // 2)): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
