@@ -14,13 +14,16 @@ def per_kernel(path):
     return acc
 
 
-fetch, write, steps = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), float(sys.argv[3])
+fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+# STEPS = auto: the fused loss forward runs exactly once per step
+steps = (float(sys.argv[3]) if sys.argv[3] != "auto" else
+         float(sum(len(v) for k, v in fetch.items() if "dice_focal_fwd_kernel" in k)))
 kernels, conv, total = {}, 0.0, 0.0
 for name in sorted(fetch, key=lambda k: -sum(fetch[k]) * 2 - sum(write.get(k, []))):
     rd, wr = 2 * sum(fetch[name]), sum(write.get(name, []))
     n = len(fetch[name])
     total += rd + wr
-    if ("conv_fwd_kernel" in name or "conv_wgrad_kernel" in name):
+    if any(k in name for k in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_wgrad_reduce_kernel", "conv_first_")):   # what bench.py times as convolution
         conv += rd + wr
     kernels[name] = {"launches_per_step": round(n / steps, 2), "hbm_read_bytes_per_launch": int(rd / n),
                      "hbm_write_bytes_per_launch": int(wr / n)}

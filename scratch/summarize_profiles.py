@@ -1,5 +1,5 @@
 """profiles/<tag>_summary.md from one profiling round (scratch/profile_round.sh):
-    python scratch/summarize_profiles.py gpurun_out/prof_round r01 STEPS_TRACE STEPS_PMC
+    python scratch/summarize_profiles.py gpurun_out/prof_round r02
 Per kernel: launches per step, average duration (kernel trace), HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE) ->
 achieved GB/s, and for the MFMA kernels the share of cycles in which the matrix pipes were busy
 (SQ_VALU_MFMA_BUSY_CYCLES summed over the 1024 SIMDs / (1024 x GRBM_GUI_ACTIVE per XCD))."""
@@ -9,7 +9,9 @@ import json
 import re
 import sys
 
-d, tag, steps_trace, steps_pmc = sys.argv[1], sys.argv[2], float(sys.argv[3]), float(sys.argv[4])
+d, tag = sys.argv[1], sys.argv[2]
+# steps in the trace: the fused loss forward runs exactly once per step
+steps_trace = sum(int(r["Calls"]) for r in csv.DictReader(open(f"{d}/trace_kernel_stats.csv")) if "dice_focal_fwd_kernel" in r["Name"])
 
 
 def pmc(path):
