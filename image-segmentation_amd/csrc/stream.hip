@@ -659,61 +659,6 @@ __device__ __forceinline__ Lerp lerp_taps(int o, int in, bool align) {
     return l;
 }
 
-// adjoint of the interpolation (gather form): every input pixel collects from the output pixels whose
-// taps include it.  For x2 up-sampling those lie in [2h-3, 2h+3] for either corner convention.
-template <typename T>
-__global__ __launch_bounds__(kThreads) void upsample_bwd_kernel(const T* __restrict__ dy, int64_t ld_dy,
-                                                                const T* __restrict__ y, int64_t ldy, int H, int W, int C,
-                                                                int relu, int align, T* __restrict__ dx, int64_t ld_dx) {
-    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
-    const PatchItem it = patch_item(blockIdx.x, threadIdx.x, H, W, cv);     // one INPUT pixel (8 channels) per thread
-    if (!it.ok) return;
-    const int h = it.h, w = it.w, v = it.v;
-    const int64_t n = it.n;
-    float wy[7], wx[7];
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const int oy = 2 * h - 3 + k, ox = 2 * w - 3 + k;
-        wy[k] = 0.f; wx[k] = 0.f;
-        if (oy >= 0 && oy < Ho) {
-            const Lerp l = lerp_taps(oy, H, align != 0);
-            wy[k] = (l.i0 == h ? l.w0 : 0.f) + (l.i1 == h ? l.w1 : 0.f);
-        }
-        if (ox >= 0 && ox < Wo) {
-            const Lerp l = lerp_taps(ox, W, align != 0);
-            wx[k] = (l.i0 == w ? l.w0 : 0.f) + (l.i1 == w ? l.w1 : 0.f);
-        }
-    }
-    float acc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
-    for (int ky = 0; ky < 7; ++ky) {
-        if (wy[ky] == 0.f) continue;
-        const int oy = 2 * h - 3 + ky;
-        float row[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) row[j] = 0.f;
-        for (int kx = 0; kx < 7; ++kx) {
-            if (wx[kx] == 0.f) continue;
-            const int ox = 2 * w - 3 + kx;
-            const int64_t op = (n * Ho + oy) * Wo + ox;
-            float d[8];
-            Elem<T>::load8(dy + op * ld_dy + v * 8, d);
-            if (relu) {
-                float f[8];
-                Elem<T>::load8(y + op * ldy + v * 8, f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) d[j] = f[j] > 0.f ? d[j] : 0.f;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) row[j] += wx[kx] * d[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += wy[ky] * row[j];
-    }
-    Elem<T>::store8(dx + ((n * H + h) * W + w) * ld_dx + v * 8, acc);
-}
-
 // ------------------------------------------------------------------------------ bilinear resize by any factor
 // align_corners=False with an explicit scale factor: ATen maps output index o to the source coordinate
 // max(ratio * (o + 0.5) - 0.5, 0) with ratio = 1 / scale_factor (upsample_bilinear2d), taps i0 = floor, i1 = min(i0 + 1, in - 1).
@@ -1002,6 +947,82 @@ __global__ __launch_bounds__(kThreads) void upsample_bwd_half_kernel(const T* __
             const Pack8 d = tile[((2 * lh + ky) * RW + 2 * lw + kx) * cg + lv];
 #pragma unroll
             for (int j = 0; j < 8; ++j) row[j] += wx[kx] * Elem<T>::to_f(d.e[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += wy[ky] * row[j];
+    }
+    Elem<T>::store8(dx + ((n * H + h) * W + w) * ld_dx + v * 8, acc);
+}
+
+// backward, either corner convention (used for align_corners=True): input pixel h is a tap of the outputs whose source
+// coordinate lies in (h-1, h+1); for x2 up-sampling with source coordinate o*(H-1)/(2H-1) those are o in [2h-2, 2h+3]
+// (the 4 of align_corners=False lie inside).  The block stages the (2*TY+4) x 20 output pixels around its TY x 8 patch in
+// LDS once (masked by the ReLU when asked, zero outside the image); every thread then gathers its 6 x 6 window from LDS with
+// the weights ATen's formula gives (rows of zero weight are skipped).
+constexpr int kUpBlockSlots = 1920;  // max over channel groups cg of (2*TY + 4) * 20 * cg with TY = 256 / (8*cg): cg = 8
+template <typename T>
+__global__ __launch_bounds__(kThreads) void upsample_bwd_block_kernel(const T* __restrict__ dy, int64_t ld_dy,
+                                                                      const T* __restrict__ y, int64_t ldy, int H, int W, int C,
+                                                                      int relu, int align, T* __restrict__ dx, int64_t ld_dx) {
+    struct alignas(16) Pack8 { T e[8]; };
+    __shared__ Pack8 tile[kUpBlockSlots];
+    const int cv = C / 8, Ho = 2 * H, Wo = 2 * W;
+    const int cg = patch_cg(cv), ty = kThreads / (8 * cg);
+    const PatchItem it = patch_item(xcd_contiguous_block(blockIdx.x, gridDim.x), threadIdx.x, H, W, cv);
+    const int lh = threadIdx.x / (cg * 8), lw = (threadIdx.x / cg) % 8, lv = threadIdx.x % cg;
+    const int h0 = it.h - lh, w0 = it.w - lw, v0 = it.v - lv;
+    const int64_t n = it.n;
+    constexpr int RW = 20;
+    const int slots = (2 * ty + 4) * RW * cg;
+    for (int s = threadIdx.x; s < slots; s += kThreads) {
+        const int vv = s % cg, px = s / cg;
+        const int ry = px / RW, rx = px - ry * RW;
+        const int oy = 2 * h0 - 2 + ry, ox = 2 * w0 - 2 + rx;
+        Pack8 val;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) val.e[j] = Elem<T>::from_f(0.f);
+        if (oy >= 0 && oy < Ho && ox >= 0 && ox < Wo) {
+            const int64_t op = (n * Ho + oy) * Wo + ox;
+            val = *reinterpret_cast<const Pack8*>(dy + op * ld_dy + (v0 + vv) * 8);
+            if (relu) {
+                const Pack8 f = *reinterpret_cast<const Pack8*>(y + op * ldy + (v0 + vv) * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) val.e[j] = Elem<T>::to_f(f.e[j]) > 0.f ? val.e[j] : Elem<T>::from_f(0.f);
+            }
+        }
+        tile[s] = val;
+    }
+    __syncthreads();
+    if (!it.ok) return;
+    const int h = it.h, w = it.w, v = it.v;
+    float wy[6], wx[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int oy = 2 * h - 2 + k, ox = 2 * w - 2 + k;
+        wy[k] = 0.f; wx[k] = 0.f;
+        if (oy >= 0 && oy < Ho) {
+            const Lerp l = lerp_taps(oy, H, align != 0);
+            wy[k] = (l.i0 == h ? l.w0 : 0.f) + (l.i1 == h ? l.w1 : 0.f);
+        }
+        if (ox >= 0 && ox < Wo) {
+            const Lerp l = lerp_taps(ox, W, align != 0);
+            wx[k] = (l.i0 == w ? l.w0 : 0.f) + (l.i1 == w ? l.w1 : 0.f);
+        }
+    }
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < 6; ++ky) {
+        if (wy[ky] == 0.f) continue;
+        float row[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) row[j] = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 6; ++kx) {
+            const Pack8 t = tile[((2 * lh + ky) * RW + 2 * lw + kx) * cg + lv];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) row[j] += wx[kx] * Elem<T>::to_f(t.e[j]);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[j] += wy[ky] * row[j];
@@ -1620,7 +1641,7 @@ extern "C" int segk_upsample2x_bwd(int dtype, const void* dy, int64_t ld_dy, con
         SEGK_LAUNCH_CHECK();
         return SEGK_OK;
     }
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((upsample_bwd_block_kernel<T>), dim3((unsigned)patch_blocks(N, H, W, C)), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)dy, ld_dy, (const T*)y, ldy, (int)H, (int)W, (int)C,
                                                      flags & 1, (flags >> 2) & 1, (T*)dx, ld_dx));
     SEGK_LAUNCH_CHECK();
