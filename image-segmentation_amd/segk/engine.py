@@ -24,11 +24,14 @@ _NO_CONV_STATS = bool(os.environ.get("SEGK_NO_CONV_STATS"))   # experiments: sep
 # kernels can run side by side and fill each other's tails and the under-occupied small layers (gradients are bitwise
 # the same either way).  On by default with one rank; SEGK_WGRAD_STREAM=0 turns it off.
 _WGRAD_STREAM = os.environ.get("SEGK_WGRAD_STREAM", "1") == "1"
+# With more than one rank the side stream stays off unless asked for (SEGK_WGRAD_STREAM_DP=1): the bucket all-reduces then wait
+# for both streams (segk/flat.py), but three concurrent streams next to RCCL's own have only been run with a one-rank group.
+_WGRAD_STREAM_DP = os.environ.get("SEGK_WGRAD_STREAM_DP", "0") == "1"
 _side_streams = {}
 
 
 def _data_parallel():
-    """More than one rank: the side stream stays off.  Bucket all-reduces would be launched from inside it, and that
+    """More than one rank: the side stream stays off by default.  Bucket all-reduces are then launched from inside it, and that
     combination cannot be exercised where only one GPU is at hand (RCCL refuses two ranks on one device)."""
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
@@ -158,7 +161,7 @@ class Runtime:
     @contextlib.contextmanager
     def side(self):
         """Run the enclosed launches on the side stream, after everything enqueued so far on the current stream."""
-        if not _WGRAD_STREAM or self.device.type != "cuda" or _data_parallel():
+        if not _WGRAD_STREAM or self.device.type != "cuda" or (_data_parallel() and not _WGRAD_STREAM_DP):
             yield
             return
         s = side_stream(self.device)

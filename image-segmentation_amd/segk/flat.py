@@ -69,7 +69,8 @@ class GradBuckets:
         if self.comm_stream is not None and dist.get_backend(self.group) != "nccl":
             # a CPU-only backend (gloo) under CUDA tensors, e.g. a rehearsal with several ranks on one card: reduce a host copy.
             # (gloo's own path for device tensors stalled for minutes per bucket when two ranks shared a GPU)
-            host = view.cpu()                                 # waits for the gradient kernels of the current stream
+            torch.cuda.synchronize(flat_grad.device)          # gradients may have been produced on two streams
+            host = view.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             view.copy_(host.mul_(1.0 / self.world))
         elif self.comm_stream is not None:
