@@ -1279,11 +1279,15 @@ static int64_t stream_blocks(int64_t M, int rows, int64_t groups) {
 }
 
 static int stats_bpg(int64_t groups, int64_t M, int64_t C) {
-    // ~16 pixel rows of work per thread at least; cap total blocks near 4096
+    // ~16 pixel rows of work per thread; at most ~2048 blocks in total
     const int64_t rows = kThreads / (C / 8);
     int64_t bpg = M / (rows * 16);
     const int64_t cap = (2048 + groups - 1) / groups;
     if (bpg > cap) bpg = cap;
+    // small tensors: a thread that walks 16 rows one after the other is a chain of 16 memory latencies on a GPU that is
+    // mostly idle; spread the rows over ~1024 blocks instead, as long as every thread keeps two rows
+    const int64_t want = (1024 + groups - 1) / groups, thin = M / (rows * 2);
+    if (bpg < want) bpg = thin < want ? (thin > bpg ? thin : bpg) : want;
     if (bpg < 1) bpg = 1;
     return (int)bpg;
 }
