@@ -399,6 +399,32 @@ def test_upsample_plain(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(1, 8, 1, 1), (2, 24, 3, 5), (1, 16, 2, 17), (1, 40, 33, 9), (1, 128, 5, 8), (2, 72, 9, 31)], ids=str)
+def test_upsample_x2_edge_shapes(dtype, shape):
+    """The block-wise x2 kernels on shapes that leave partial patches in every direction, one-pixel images and every
+    channel grouping (1, 2, 4 and 8 vectors of 8 channels per block), both corner conventions, with and without the
+    fused ReLU mask in the backward."""
+    from segk import ops
+    N, C, H, W = shape
+    x, dy = rnd((N, C, H, W), dtype, 45), rnd((N, C, 2 * H, 2 * W), dtype, 46)
+    for align in (False, True):
+        for relu in (False, True):
+            out = ops.Act(torch.zeros(N, 2 * H, 2 * W, C + 8, dtype=dtype, device="cuda"), 8, C)
+            ops.upsample_fwd(to_act(x, dtype), out, relu=relu, align=align)
+            xd = x.double().requires_grad_(True)
+            ref = F.interpolate(xd, scale_factor=2, mode="bilinear", align_corners=align)
+            got = from_act(out)
+            report(f"up_fwd_ac{align}_relu{relu}", got, (F.relu(ref) if relu else ref).float(), **TOL[dtype])
+            # the backward masks with the sign of the STORED output (a value within rounding of zero may have either sign
+            # there), so the reference adjoint is taken with exactly that mask
+            g = dy.double() * (got > 0).double() if relu else dy.double()
+            ref.backward(g)
+            dx = ops.Act.empty(N, H, W, C, dtype, "cuda")
+            ops.upsample_bwd(to_act(dy, dtype), out if relu else None, dx, relu=relu, align=align)
+            report(f"up_bwd_ac{align}_relu{relu}", from_act(dx), xd.grad.float(), **TOL[dtype])
+
+
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_maxpool(dtype):
     from segk import ops
     N, C, H, W = 2, 64, 12, 16
