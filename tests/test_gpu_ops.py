@@ -473,6 +473,23 @@ def test_head_and_colsum(dtype):
     report("colsum_accum", s.cpu(), 2 * x.double().sum((0, 2, 3)).float(), rtol=1e-5, atol=2e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("case", [(1, 8, 5, 7, 1), (2, 24, 9, 31, 3), (3, 64, 16, 17, 4), (1, 136, 6, 50, 8), (1, 1024, 3, 11, 8), (2, 64, 64, 80, 4)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_head_forward_row_staging(dtype, case):
+    """1x1 head forward over the widths that select every staging mode (256, 128, 64 pixel rows per round in LDS, and rows too
+    long for LDS), pixel counts that are not multiples of a round, 1..8 classes, input living in a channel slice."""
+    from segk import ops
+    N, Cin, H, W, Cout = case
+    x = rnd((N, Cin, H, W), dtype, 65)
+    w, b = rnd((Cout, Cin), torch.float32, 66, 0.3), rnd((Cout,), torch.float32, 67)
+    xa = to_act(x, dtype, ld=Cin + 16, c0=8)
+    logits = torch.full((N, Cout, H, W), float("nan"), device="cuda")
+    ops.head_fwd(xa, w.cuda(), b.cuda(), logits)
+    ref = F.conv2d(x.double(), w.double()[:, :, None, None], b.double())
+    report("head_fwd", logits.cpu(), ref.float(), rtol=2e-5, atol=2e-5 * float(ref.abs().max()))
+
+
 def test_copy_slice_and_adam():
     from segk import ops
     a = rnd((2, 40, 6, 6), torch.float32, 71)
