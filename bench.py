@@ -242,7 +242,7 @@ def main():
         if args.side == 384:
             args.side = 256
         if args.batch == 32:
-            args.batch = 4
+            args.batch = 12                        # the reference's own batch size (train_midlslice.py:24)
         gflop = detectmid_gflop(model, args.depth, args.side)
     elif args.model == "unetpp":
         from models.unetplusplus import Nested_UNet
