@@ -169,7 +169,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="slices per GPU")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="slices (volumes) per GPU; default: 32 for the UNet-VGG headline configuration, 16 for UNet++ and UNetSimple, "
+                         "8 for SpiderNet, 12 for the 3-D classifier (the batch sizes of BASELINE.json and of the reference's scripts)")
     ap.add_argument("--side", type=int, default=384)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--model", default="unetvgg", choices=["unetvgg", "unetvgg_convtrans", "unetpp", "detectmid", "unetsimple", "spidernet"])
@@ -208,6 +210,9 @@ def main():
         if int(os.environ.get("RANK", "0")) == 0:
             print(json.dumps({"dry_run": True, "n_gpus": seen, "steps": args.steps, "warmup": args.warmup}), flush=True)
         return
+    if args.batch is None:
+        # UNet-VGG 32 and UNet++ 16 as BASELINE.json quotes them; the 3-D classifier at the reference's own 12 (train_midlslice.py:24)
+        args.batch = {"unetpp": 16, "unetsimple": 16, "spidernet": 8, "detectmid": 12}.get(args.model, 32)
     if args.strong:
         if args.batch % world:
             sys.exit(f"bench.py --strong: global batch {args.batch} does not divide over {world} ranks")
@@ -241,8 +246,6 @@ def main():
         model = DetectMid(in_classes=1)
         if args.side == 384:
             args.side = 256
-        if args.batch == 32:
-            args.batch = 12                        # the reference's own batch size (train_midlslice.py:24)
         gflop = detectmid_gflop(model, args.depth, args.side)
     elif args.model == "unetpp":
         from models.unetplusplus import Nested_UNet
