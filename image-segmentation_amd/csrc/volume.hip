@@ -286,6 +286,108 @@ __global__ __launch_bounds__(kVThreads) void avgpool3d_bwd_kernel(const T* __res
     }
 }
 
+// ------------------------------------------------------------------------------ classifier tail
+// Global average over the V voxels of every sample ([N, V, ld] slice-major, 8 channels per thread) -> fp32 [N, C]; its
+// adjoint spreads dout / V over the voxels.  The tensors behind the last dense block hold a few thousand values.
+template <typename T>
+__global__ __launch_bounds__(kVThreads) void rows_mean_fwd_kernel(const T* __restrict__ x, int64_t ld, int64_t V, int C,
+                                                                  float* __restrict__ out) {
+    const int cv = C / 8;
+    const int64_t n = blockIdx.x;
+    for (int v = threadIdx.x; v < cv; v += kVThreads) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        for (int64_t p = 0; p < V; ++p) {            // fixed order: reproducible
+            float a[8];
+            Elem<T>::load8(x + (n * V + p) * ld + v * 8, a);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[n * C + v * 8 + j] = acc[j] / (float)V;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kVThreads) void rows_mean_bwd_kernel(const float* __restrict__ dout, int64_t V, int C,
+                                                                  T* __restrict__ dx, int64_t ld) {
+    const int cv = C / 8;
+    const int64_t n = blockIdx.y;                            // gridDim.y = N
+    for (int64_t i = (int64_t)blockIdx.x * kVThreads + threadIdx.x; i < V * cv; i += (int64_t)gridDim.x * kVThreads) {
+        const int v = (int)(i % cv);
+        const int64_t p = i / cv;
+        float g[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = dout[n * C + v * 8 + j] / (float)V;
+        Elem<T>::store8(dx + (n * V + p) * ld + v * 8, g);
+    }
+}
+
+// nn.Linear on a handful of fp32 rows: y[n][o] = b[o] + sum_k x[n][k] * w[o][k].  One workgroup per output feature; the
+// threads stride over k with one accumulator per row (rows in chunks of 16), a fixed-order tree adds the threads.
+constexpr int kLinRows = 16;
+__device__ __forceinline__ float block_sum_f(float v, float* sm) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float s = 0.f;
+    for (int i = 0; i < kVThreads / 64; ++i) s += sm[i];
+    return s;
+}
+
+__global__ __launch_bounds__(kVThreads) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ b, int N, int K, int O,
+                                                               float* __restrict__ y) {
+    __shared__ float sm[kVThreads / 64];
+    const int o = blockIdx.x;
+    for (int n0 = 0; n0 < N; n0 += kLinRows) {
+        float acc[kLinRows];
+#pragma unroll
+        for (int r = 0; r < kLinRows; ++r) acc[r] = 0.f;
+        for (int k = threadIdx.x; k < K; k += kVThreads) {
+            const float wv = w[(int64_t)o * K + k];
+#pragma unroll
+            for (int r = 0; r < kLinRows; ++r)
+                if (n0 + r < N) acc[r] += x[(int64_t)(n0 + r) * K + k] * wv;
+        }
+#pragma unroll
+        for (int r = 0; r < kLinRows; ++r) {
+            const float s = block_sum_f(acc[r], sm);
+            if (threadIdx.x == 0 && n0 + r < N) y[(int64_t)(n0 + r) * O + o] = s + (b ? b[o] : 0.f);
+        }
+    }
+}
+
+// dw[o][k] = sum_n dy[n][o] * x[n][k] (threads over k), db[o] = sum_n dy[n][o]; one workgroup per output feature
+__global__ __launch_bounds__(kVThreads) void linear_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N,
+                                                                 int K, int O, float* __restrict__ dw, float* __restrict__ db,
+                                                                 int accumulate) {
+    const int o = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += kVThreads) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dy[(int64_t)n * O + o] * x[(int64_t)n * K + k];
+        float* dst = dw + (int64_t)o * K + k;
+        *dst = accumulate ? *dst + s : s;
+    }
+    if (db && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dy[(int64_t)n * O + o];
+        db[o] = accumulate ? db[o] + s : s;
+    }
+}
+
+// dx[n][k] = sum_o dy[n][o] * w[o][k]; workgroup = (k tile, row), threads over k (coalesced rows of w)
+__global__ __launch_bounds__(kVThreads) void linear_dgrad_kernel(const float* __restrict__ w, const float* __restrict__ dy, int K,
+                                                                 int O, float* __restrict__ dx) {
+    const int n = blockIdx.y, k = blockIdx.x * kVThreads + threadIdx.x;
+    if (k >= K) return;
+    float s = 0.f;
+    for (int o = 0; o < O; ++o) s += dy[(int64_t)n * O + o] * w[(int64_t)o * K + k];
+    dx[(int64_t)n * K + k] = s;
+}
+
 static int check_vol(const char* who, const void* p, int64_t ld, int64_t C, int dtype) {
     if (!p) return fail(SEGK_EINVAL, "%s: null activation pointer", who);
     if (dtype != SEGK_F32 && dtype != SEGK_BF16) return fail(SEGK_EINVAL, "%s: unknown dtype %d", who, dtype);
@@ -415,5 +517,54 @@ extern "C" int segk_avgpool3d_bwd(int dtype, const void* dy, int64_t ld_dy, int6
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((avgpool3d_bwd_kernel<T>), dim3(vgrid(items)), dim3(kVThreads), 0, (hipStream_t)stream,
                                                      (const T*)dy, ld_dy, N, (int)D, (int)H, (int)W, (int)C, (T*)dx, ld_dx, (flags >> 1) & 1));
     SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_rows_mean_fwd(int dtype, const void* x, int64_t ld, int64_t N, int64_t V, int64_t C, float* out, int dev,
+                                  void* stream) {
+    if (int rc = check_vol("rows_mean_fwd", x, ld, C, dtype)) return rc;
+    SEGK_REQUIRE(out && N > 0 && N < 65536 && V > 0, SEGK_EINVAL, "rows_mean_fwd: bad arguments");
+    SEGK_USE_DEVICE(dev);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rows_mean_fwd_kernel<T>), dim3((unsigned)N), dim3(kVThreads), 0, (hipStream_t)stream,
+                                                     (const T*)x, ld, V, (int)C, out));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_rows_mean_bwd(int dtype, const float* dout, int64_t N, int64_t V, int64_t C, void* dx, int64_t ld, int dev,
+                                  void* stream) {
+    if (int rc = check_vol("rows_mean_bwd", dx, ld, C, dtype)) return rc;
+    SEGK_REQUIRE(dout && N > 0 && N < 65536 && V > 0, SEGK_EINVAL, "rows_mean_bwd: bad arguments");
+    SEGK_USE_DEVICE(dev);
+    const int gx = vgrid(V * (C / 8), 1024);
+    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((rows_mean_bwd_kernel<T>), dim3((unsigned)gx, (unsigned)N), dim3(kVThreads), 0,
+                                                     (hipStream_t)stream, dout, V, (int)C, (T*)dx, ld));
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_linear_fwd(const float* x, const float* w, const float* bias, int64_t N, int64_t K, int64_t O, float* y, int dev,
+                               void* stream) {
+    SEGK_REQUIRE(x && w && y, SEGK_EINVAL, "linear_fwd: null pointer");
+    SEGK_REQUIRE(N > 0 && K > 0 && O > 0 && N < (1 << 20) && K < (1 << 24) && O < (1 << 24), SEGK_ESHAPE, "linear_fwd: bad shape");
+    SEGK_USE_DEVICE(dev);
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)O), dim3(kVThreads), 0, (hipStream_t)stream, x, w, bias, (int)N, (int)K, (int)O, y);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+extern "C" int segk_linear_bwd(const float* x, const float* w, const float* dy, int64_t N, int64_t K, int64_t O, float* dx, float* dw,
+                               float* dbias, int flags, int dev, void* stream) {
+    SEGK_REQUIRE(x && w && dy && dw, SEGK_EINVAL, "linear_bwd: null pointer");
+    SEGK_REQUIRE(N > 0 && N < 65536 && K > 0 && O > 0 && K < (1 << 24) && O < (1 << 24), SEGK_ESHAPE, "linear_bwd: bad shape");
+    SEGK_USE_DEVICE(dev);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(linear_wgrad_kernel, dim3((unsigned)O), dim3(kVThreads), 0, st, x, dy, (int)N, (int)K, (int)O, dw, dbias, (flags >> 1) & 1);
+    SEGK_LAUNCH_CHECK();
+    if (dx) {
+        hipLaunchKernelGGL(linear_dgrad_kernel, dim3((unsigned)((K + kVThreads - 1) / kVThreads), (unsigned)N), dim3(kVThreads), 0, st, w, dy,
+                           (int)K, (int)O, dx);
+        SEGK_LAUNCH_CHECK();
+    }
     return SEGK_OK;
 }

@@ -69,6 +69,10 @@ _PROTOS = {
     "segk_maxpool3d_bwd": (I, [I, P, L, P, L, L, L, L, L, P, L, I, I, P]),
     "segk_avgpool3d_fwd": (I, [I, P, L, L, L, L, L, L, P, L, I, P]),
     "segk_avgpool3d_bwd": (I, [I, P, L, L, L, L, L, L, P, L, I, I, P]),
+    "segk_rows_mean_fwd": (I, [I, P, L, L, L, L, P, I, P]),
+    "segk_rows_mean_bwd": (I, [I, P, L, L, L, P, L, I, P]),
+    "segk_linear_fwd": (I, [P, P, P, L, L, L, P, I, P]),
+    "segk_linear_bwd": (I, [P, P, P, L, L, L, P, P, P, I, I, P]),
     "segk_relu_bwd": (I, [I, P, L, P, L, L, L, P, L, I, P]),
     "segk_head1x1_fwd": (I, [I, P, L, L, L, L, P, P, L, P, I, P]),
     "segk_head1x1_bwd_workspace": (Z, [L, L, L, L]),

@@ -155,27 +155,24 @@ class Runtime3D(Runtime):
         return self.avgpool3d(h, D, out=out)
 
     def pooled_features(self, x, D, norm_prefix):
-        """Final BatchNorm3d -> ReLU -> global average pool (models/densenet3d.py:129,153-157) -> fp32 [N, C].
-        The mean over the few voxels that are left (and its adjoint) is bookkeeping on a [N, voxels, C] view."""
+        """Final BatchNorm3d -> ReLU -> global average pool (models/densenet3d.py:129,153-157) -> fp32 [N, C]."""
         h = self.bn_relu(x, norm_prefix)
         a = h.act
         N = a.N // D
-        vox = D * a.H * a.W
-        feats = a.buf.view(N, vox, a.ld)[:, :, a.c0:a.c0 + a.C].float().mean(dim=1)
+        feats = ops.rows_mean_fwd(a, N)
 
         def bwd(dfeats):
-            g = self.grad_of(a)
-            g.buf.view(N, vox, g.ld)[:, :, g.c0:g.c0 + g.C].copy_((dfeats / vox).unsqueeze(1).expand(N, vox, a.C))
+            ops.rows_mean_bwd(dfeats.contiguous(), self.grad_of(a))
             h.ready = True
         return feats, bwd
 
     # ---------------------------------------------------------------- fully connected tail
     def linear_tail(self, feats, feats_bwd, layers, squeeze_last=False):
         """Chain of nn.Linear layers on the pooled features (models/densenet3d.py:139,158; models/resnt.py:34-35,41-44):
-        plain library GEMMs on [N, <=1664] fp32 rows.  `layers`: (weight name, bias name) pairs."""
+        [N, <=1664] fp32 rows.  `layers`: (weight name, bias name) pairs."""
         acts = [feats]
         for wn, bn_ in layers:
-            acts.append(torch.addmm(self.p[bn_].detach(), acts[-1], self.p[wn].detach().t()))
+            acts.append(ops.linear_fwd(acts[-1], self.p[wn].detach().contiguous(), self.p[bn_].detach()))
         out = acts[-1].squeeze(-1) if squeeze_last else acts[-1]
         self._tail = (acts, feats_bwd, layers, squeeze_last)
         return out
@@ -185,13 +182,12 @@ class Runtime3D(Runtime):
         d = dout.float()
         if squeeze_last:
             d = d.unsqueeze(-1)
+        d = d.contiguous()
         for k in range(len(layers) - 1, -1, -1):
             wn, bn_ = layers[k]
-            w = self.p[wn].detach()
+            w = self.p[wn].detach().contiguous()
             gw, gb = self.alloc_grad(wn, w), self.alloc_grad(bn_, self.p[bn_])
-            torch.mm(d.t(), acts[k], out=gw)
-            torch.sum(d, dim=0, out=gb)
+            d = ops.linear_bwd(acts[k], w, d, gw, gb)
             self._emit(wn, gw)
             self._emit(bn_, gb)
-            d = d @ w
         feats_bwd(d)

@@ -581,3 +581,44 @@ def avgpool3d_bwd(dy, dx, D, accumulate=False):
     call("segk_avgpool3d_bwd", dt(dx.dtype), dy.ptr, dy.ld, dx.N // D, D, dx.H, dx.W, dx.C, dx.ptr, dx.ld,
          ACCUM if accumulate else 0, dev, st)
     return dx
+
+
+# ------------------------------------------------------------------------------------ classifier tail
+def rows_mean_fwd(x, N):
+    """fp32 [N, C] mean over the x.P // N pixels (voxels) of every sample of the slice-major Act x."""
+    dev, st = _env(x.buf)
+    out = torch.empty(N, x.C, dtype=torch.float32, device=x.device)
+    call("segk_rows_mean_fwd", dt(x.dtype), x.ptr, x.ld, N, x.P // N, x.C, out.data_ptr(), dev, st)
+    return out
+
+
+def rows_mean_bwd(dout, dx):
+    """Adjoint of rows_mean_fwd into the Act dx (overwrites)."""
+    N = dout.shape[0]
+    dev, st = _env(dx.buf)
+    call("segk_rows_mean_bwd", dt(dx.dtype), dout.data_ptr(), N, dx.P // N, dx.C, dx.ptr, dx.ld, dev, st)
+    return dx
+
+
+def linear_fwd(x, w, bias):
+    """x [N, K] @ w [O, K]^T + bias, fp32."""
+    N, K = x.shape
+    O = w.shape[0]
+    assert x.dtype == w.dtype == torch.float32 and x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+    dev, st = _env(x)
+    y = torch.empty(N, O, dtype=torch.float32, device=x.device)
+    call("segk_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), N, K, O, y.data_ptr(), dev, st)
+    return y
+
+
+def linear_bwd(x, w, dy, dw, dbias=None, want_dx=True, accumulate=False):
+    """-> dx [N, K] (or None); dw [O, K] and dbias [O] are written (or added to)."""
+    N, K = x.shape
+    O = w.shape[0]
+    assert dy.shape == (N, O) and dy.dtype == torch.float32 and dy.is_contiguous() and dw.is_contiguous()
+    dev, st = _env(x)
+    dx = torch.empty(N, K, dtype=torch.float32, device=x.device) if want_dx else None
+    call("segk_linear_bwd", x.data_ptr(), w.data_ptr(), dy.data_ptr(), N, K, O, _p(dx), dw.data_ptr(), _p(dbias),
+         ACCUM if accumulate else 0, dev, st)
+    return dx
+

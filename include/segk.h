@@ -458,6 +458,24 @@ int segk_adam_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float beta1, float beta2, float eps, float weight_decay, int64_t step, float grad_scale,
                    int dev, void* stream);
 
+/* ---- classifier tail of the 3-D middle-slice network ------------------------------------------
+ * out[n][c] (fp32) = mean over the V voxels of sample n of x[(n*V + v)*ld + c]: the global average pool behind the
+ * last BatchNorm3d + ReLU (F.adaptive_avg_pool3d(.., 1), models/densenet3d.py:153-157); _bwd is its adjoint
+ * (dx = dout / V at every voxel, overwriting).                                                     */
+int segk_rows_mean_fwd(int dtype, const void* x, int64_t ld, int64_t N, int64_t V, int64_t C, float* out, int dev,
+                       void* stream);
+int segk_rows_mean_bwd(int dtype, const float* dout, int64_t N, int64_t V, int64_t C, void* dx, int64_t ld, int dev,
+                       void* stream);
+
+/* y[N][O] = x[N][K] w[O][K]^T + bias (fp32, contiguous; bias may be NULL)
+ * replaces: nn.Linear forward (models/densenet3d.py:139,158; models/resnt.py:34-35,41-44) on the pooled features.  */
+int segk_linear_fwd(const float* x, const float* w, const float* bias, int64_t N, int64_t K, int64_t O, float* y, int dev,
+                    void* stream);
+/* dw[O][K] = dy^T x, dbias[O] = column sums of dy (optional), dx[N][K] = dy w (optional); flags bit1: dw/dbias += .
+ * Fixed summation order (deterministic).   replaces: nn.Linear backward.                           */
+int segk_linear_bwd(const float* x, const float* w, const float* dy, int64_t N, int64_t K, int64_t O, float* dx, float* dw,
+                    float* dbias, int flags, int dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -154,6 +154,45 @@ def test_pools3d(dtype, shape):
         report("avgpool3d_bwd", from_vol(dx, N), xr.grad, **TOL[dtype])
 
 
+@pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 1664, 2, 4, 4), (3, 40, 1, 1, 1), (1, 256, 4, 3, 5)], ids=str)
+def test_global_average_pool_of_a_volume(dtype, shape):
+    """F.adaptive_avg_pool3d(x, 1) of models/densenet3d.py:153-157 and its adjoint."""
+    from segk import ops
+    N, C, D, H, W = shape
+    x = rnd(shape, dtype, 31)
+    xa = to_vol(x, dtype, ld=C + 8, c0=8)
+    got = ops.rows_mean_fwd(xa, N)
+    report("mean", got.cpu(), x.double().mean(dim=(2, 3, 4)).float(), rtol=1e-5, atol=1e-5)
+    dout = rnd((N, C), torch.float32, 32)
+    dxa = ops.Act(torch.full_like(xa.buf, float("nan")), 8, C)
+    ops.rows_mean_bwd(dout.cuda(), dxa)
+    want = (dout / (D * H * W))[:, :, None, None, None].expand(shape)
+    report("mean_bwd", from_vol(dxa, N, C), want, **TOL[dtype])
+
+
+@pytest.mark.parametrize("case", [(2, 1664, 1000), (12, 1000, 80), (1, 8, 1), (37, 300, 5)], ids=lambda c: "x".join(map(str, c)))
+def test_linear_layers_of_the_classifier_tail(case):
+    """nn.Linear forward / backward (models/densenet3d.py:139,158; models/resnt.py:34-35) on the pooled fp32 rows."""
+    from segk import ops
+    N, K, O = case
+    x, w, b = rnd((N, K), torch.float32, 33), rnd((O, K), torch.float32, 34, K ** -0.5), rnd((O,), torch.float32, 35)
+    dy = rnd((N, O), torch.float32, 36)
+    y = ops.linear_fwd(x.cuda(), w.cuda(), b.cuda())
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    ref = F.linear(xd, wd, bd)
+    report("linear_fwd", y.cpu(), ref.float(), rtol=1e-5, atol=1e-5)
+    ref.backward(dy.double())
+    dw, db = torch.full((O, K), float("nan"), device="cuda"), torch.full((O,), float("nan"), device="cuda")
+    dx = ops.linear_bwd(x.cuda(), w.cuda(), dy.cuda(), dw, db)
+    report("linear_dx", dx.cpu(), xd.grad.float(), rtol=1e-5, atol=1e-5)
+    report("linear_dw", dw.cpu(), wd.grad.float(), rtol=1e-5, atol=1e-5)
+    report("linear_db", db.cpu(), bd.grad.float(), rtol=1e-5, atol=1e-5)
+    ops.linear_bwd(x.cuda(), w.cuda(), dy.cuda(), dw, db, want_dx=False, accumulate=True)
+    report("linear_dw_accumulated", dw.cpu(), 2 * wd.grad.float(), rtol=1e-5, atol=2e-5)
+    report("linear_db_accumulated", db.cpu(), 2 * bd.grad.float(), rtol=1e-5, atol=2e-5)
+
+
 def _run_detectmid(name, dtype, kw, shape):
     from models.resnt import DetectMid
     from oracle.ref_models import hash_init_, synthetic_volumes
