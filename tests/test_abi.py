@@ -57,3 +57,26 @@ def test_argument_validation_needs_no_gpu():
         _lib.call("segk_maxpool2x2_fwd", _lib.SEGK_F32, 16, 8, 1, 3, 4, 8, 16, 8, 0, None)
     with pytest.raises(_lib.SegkError, match="aligned"):
         _lib.call("segk_norm_apply", _lib.SEGK_F32, 4, 8, 1, 16, 8, 16, None, None, 0, 16, 8, 0, None)
+    # entry points added for the first convolution, the norm-backward sums, the static-scratch loss and the classifier tail
+    F32, BF16 = _lib.SEGK_F32, _lib.SEGK_BF16
+    with pytest.raises(_lib.SegkError, match="SEGK_E"):       # Cin of the direct first convolution is 1..3
+        _lib.call("segk_conv_first_fwd", 16, 1, 4, 16, 16, 16, None, 64, 16, BF16, 64, None, 0, 0, None)
+    with pytest.raises(_lib.SegkError, match="SEGK_E"):       # ... and it writes bf16 only
+        _lib.call("segk_conv_first_fwd", 16, 1, 3, 16, 16, 16, None, 64, 16, F32, 64, None, 0, 0, None)
+    with pytest.raises(_lib.SegkError, match="conv_dgrad_norm"):   # z, stats and partials are mandatory
+        _lib.call("segk_conv_dgrad_norm", BF16, 9, 16, 64, 64, 1, 16, 16, 16, 64, 16, 64, None, 64, None, None, None, None, 0, None)
+    with pytest.raises(_lib.SegkError, match="frozen"):
+        _lib.call("segk_norm_bwd_finish", F32, 16, 4, 16, 8, 16, 8, 64, 8, 16, None, None, 4, 16, 8, None, None, 16, 1 << 20, 0, None)
+    with pytest.raises(_lib.SegkError, match="SEGK_EWORKSPACE"):
+        _lib.call("segk_norm_bwd_finish", F32, 16, 4096, 16, 8, 16, 8, 64, 8, 16, None, None, 1, 16, 8, None, None, 16, 16, 0, None)
+    with pytest.raises(_lib.SegkError, match="static scratch"):    # more block partials than the 1 MiB array holds
+        _lib.call("segk_dice_focal_fwd_static", 16, F32, 16, None, 65535, 8, 4096, 2.0, None, 0, 16, 16, None, 0, None)
+    with pytest.raises(_lib.SegkError, match="SEGK_ESHAPE"):
+        _lib.call("segk_linear_fwd", 16, 16, None, 4, 0, 8, 16, 0, None)
+    with pytest.raises(_lib.SegkError, match="SEGK_EINVAL"):
+        _lib.call("segk_linear_bwd", 16, 16, None, 4, 8, 8, None, 16, None, 0, 0, None)
+    with pytest.raises(_lib.SegkError, match="SEGK_E"):
+        _lib.call("segk_rows_mean_fwd", BF16, 16, 12, 2, 4, 12, 16, 0, None)     # 12 channels: not a multiple of 8
+    assert _lib.query("segk_norm_bwd_finish_workspace", 4096, 64) >= 2 * 64 * 4
+    assert _lib.query("segk_conv_first_stat_rows", 32, 384, 384) > 0
+
