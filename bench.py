@@ -366,7 +366,7 @@ def main():
                                     if args.model == "detectmid" else
                                     f"{args.model}{' deep supervision: 4 heads on x(0,1)..x(0,4), summed Dice/focal' if args.deep_sup else ''} {args.side}x{args.side}, "
                                     f"{n_classes} classes, {args.batch} slices/GPU, fwd + fused Dice/focal loss + bwd + ")
-                                   + f"{'bucketed RCCL all-reduce + ' if world > 1 else ''}fused Adam",
+                                   + f"{('bucketed ' + ('RCCL' if args.backend == 'nccl' else args.backend) + ' all-reduce + ') if world > 1 else ''}fused Adam",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "random_init_weights": True,
                        "final_loss": round(final_loss, 5), "h2d_ms_per_batch": round(h2d_ms, 3),
                        "slices_per_s_without_optimizer_step": round(world * args.batch * k2 / no_opt, 2),
