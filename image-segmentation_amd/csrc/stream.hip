@@ -1040,7 +1040,12 @@ __global__ __launch_bounds__(kThreads) void copy_slice_kernel(const T* __restric
         const int v = (int)(i % cv);
         const int64_t p = i / cv;
         float a[8];
-        Elem<T>::load8(src + p * ld_src + v * 8, a);
+        if (src) {
+            Elem<T>::load8(src + p * ld_src + v * 8, a);
+        } else {                                         // no source: fill the slice with zeros
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = 0.f;
+        }
         if (accumulate) {
             float b[8];
             Elem<T>::load8(dst + p * ld_dst + v * 8, b);
@@ -1705,9 +1710,10 @@ extern "C" int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int6
 
 extern "C" int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t P, int64_t C,
                                int flags, int dev, void* stream) {
-    SEGK_CHECK_ACT("copy_slice(src)", src, ld_src, C, dtype);
+    if (src) SEGK_CHECK_ACT("copy_slice(src)", src, ld_src, C, dtype);
     SEGK_CHECK_ACT("copy_slice(dst)", dst, ld_dst, C, dtype);
     SEGK_REQUIRE(P > 0, SEGK_ESHAPE, "copy_slice: bad shape");
+    SEGK_REQUIRE(src || !(flags & 2), SEGK_EINVAL, "copy_slice: accumulating zeros is a no-op: pass a source");
     SEGK_USE_DEVICE(dev);
     SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((copy_slice_kernel<T>), dim3(grid_for(P * (C / 8))), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)src, ld_src, (T*)dst, ld_dst, P, (int)C, (flags >> 1) & 1));

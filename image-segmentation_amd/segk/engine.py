@@ -413,7 +413,7 @@ class Runtime:
                 assert self.exports, "mixed gradient readiness inside one concat segment"
                 for m in members:
                     if not m.ready:
-                        self.grad_of(m.act).nchw().zero_()
+                        ops.zero_slice(self.grad_of(m.act))
                         m.ready = True
                 return True
             return r[0]

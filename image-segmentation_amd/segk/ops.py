@@ -444,6 +444,13 @@ def copy_slice(src, dst, accumulate=False):
     return dst
 
 
+def zero_slice(dst):
+    """Zero the channel slice `dst` of its buffer (16-byte stores per pixel; a strided torch fill runs at half the rate)."""
+    dev, st = _env(dst.buf)
+    call("segk_copy_slice", dt(dst.dtype), None, 0, dst.ptr, dst.ld, dst.P, dst.C, 0, dev, st)
+    return dst
+
+
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     dev, st = _env(param)
     call("segk_adam_step", param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr(), param.numel(), lr,

@@ -415,7 +415,8 @@ int segk_colsum(int dtype, const void* x, int64_t ld, int64_t P, int64_t C, floa
                 void* workspace, size_t workspace_bytes, int dev, void* stream);
 
 /* dst[p, c] (+)= src[p, c] for a [P,C] channel slice (gradient fan-in of a tensor with several
- * consumers, e.g. the dense skips of models/unetplusplus.py:64-79).  flags bit1: accumulate.       */
+ * consumers, e.g. the dense skips of models/unetplusplus.py:64-79).  flags bit1: accumulate.
+ * src == NULL: the slice is filled with zeros.                                                     */
 int segk_copy_slice(int dtype, const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t P,
                     int64_t C, int flags, int dev, void* stream);
 

@@ -492,6 +492,9 @@ def test_head_forward_row_staging(dtype, case):
 
 def test_copy_slice_and_adam():
     from segk import ops
+    z = ops.Act(torch.full((2, 5, 7, 48), 3.0, dtype=torch.bfloat16, device="cuda"), 16, 24)
+    ops.zero_slice(z)
+    assert float(z.buf[..., 16:40].abs().max()) == 0 and float((z.buf[..., :16] - 3).abs().max()) == 0 and float((z.buf[..., 40:] - 3).abs().max()) == 0
     a = rnd((2, 40, 6, 6), torch.float32, 71)
     src = to_act(a, torch.float32)
     dst = ops.Act(torch.ones(2, 6, 6, 64, device="cuda"), 16, 40)
