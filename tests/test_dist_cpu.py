@@ -60,17 +60,18 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_world2():
+@pytest.mark.parametrize("world", [2, 4])
+def test_bucketed_allreduce(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
-    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+    assert sorted(q.get(timeout=5)[0] for _ in range(world)) == list(range(world))
 
 
 def test_bucket_partition_covers_flat_buffer():
