@@ -773,6 +773,7 @@ struct WgradArgs {
     // volumes (depth > 0): nkd times the workgroups, one share per depth tap kdi; x is read from slice n + kdi - nkd/2 of
     // the volume that holds slice n (zero outside); slab gets a leading [nkd] dimension
     int depth = 0, nkd = 3;
+    int xcd_remap = 1;
 };
 
 template <typename T> __device__ __forceinline__ int wg_swz(int pix);
@@ -802,11 +803,27 @@ __global__ __launch_bounds__(kConvThreads, 2) void conv_wgrad_kernel(const Wgrad
     const int g = lane >> 4, l15 = lane & 15;
     const int wi = wave / GJ, wj = wave % GJ;
 
+    // Workgroups that share a pixel range (same split, different channel-block pairs) read the same dy and x pixels:
+    // blocks go to the 8 XCDs round-robin, so renumber them XCD-contiguously over a list with the split slowest --
+    // each XCD's L2 then holds one or two splits' pixels instead of every split's (the split count is not a multiple
+    // of 8 for the 192- and 768-channel concat inputs).
     int b = blockIdx.x;
-    const int split = b % a.splits; b /= a.splits;
-    const int chunk = b % a.nch; b /= a.nch;
-    const int cb = b % a.ncb;
-    const int kdi = b / a.ncb;              // 0 unless a volume convolution (then 0..2)
+    const int npairs = a.nch * a.ncb;
+    int kdi, split, chunk, cb;                 // kdi: 0 unless a volume convolution (then 0..2)
+    if (a.xcd_remap) {
+        const int G = gridDim.x, base = G >> 3, rem = G & 7, x = b & 7;
+        b = x * base + (x < rem ? x : rem) + (b >> 3);
+        kdi = b / (npairs * a.splits);
+        b -= kdi * npairs * a.splits;
+        split = b / npairs; b -= split * npairs;
+        chunk = b % a.nch;
+        cb = b / a.nch;
+    } else {                                   // plain order, split fastest
+        split = b % a.splits; b /= a.splits;
+        chunk = b % a.nch; b /= a.nch;
+        cb = b % a.ncb;
+        kdi = b / a.ncb;
+    }
     const int kd = a.depth > 0 ? kdi - a.nkd / 2 : 0;
 
     const bool s0 = chunk < a.nch0;
@@ -1466,6 +1483,8 @@ extern "C" int segk_conv_wgrad(int dtype, int taps, const void* x0, int64_t ld0,
     a.splits = wgrad_splits(ntiles, a.ncb, a.nch);
     a.tiles_per_split = (int)((ntiles + a.splits - 1) / a.splits);
     a.slab = (float*)workspace;
+    static const bool no_remap = getenv("SEGK_WGRAD_NO_XCD_REMAP") != nullptr;   // experiment switch: plain block order
+    a.xcd_remap = no_remap ? 0 : 1;
     hipStream_t st = (hipStream_t)stream;
     const unsigned grid = (unsigned)((int64_t)a.ncb * a.nch * a.splits);
     launch_wgrad_any(dtype, taps, a, grid, st, Cout, C0);
