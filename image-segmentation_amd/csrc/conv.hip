@@ -1384,7 +1384,8 @@ static int conv_fwd_impl(int dtype, int taps, const void* x0, int64_t ld0, int64
                          (ldy1 * esize(dtype)) % 16 == 0 && !mask),
                  SEGK_ESHAPE, "conv_fwd: second output needs 0 < split < Cout, split a multiple of 8, aligned y1, and no mask");
     SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_fwd: taps must be 1 or 9");
-    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_fwd: bad N/H/W");
+    // the halo tables pack (pixel index << 3 | slot) into a signed 32-bit register
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 28), SEGK_ESHAPE, "conv_fwd: bad N/H/W (at most 2^28 - 1 pixels per launch)");
     SEGK_REQUIRE(w_packed && y && aligned16(w_packed), SEGK_EINVAL, "conv_fwd: null or misaligned weights/output");
     SEGK_REQUIRE(Cout > 0 && Cout % 8 == 0 && (y1 || ldy >= Cout), SEGK_ESHAPE, "conv_fwd: Cout %lld must be a multiple of 8 and <= ldy", (long long)Cout);
     SEGK_REQUIRE(aligned16(y) && (ldy * esize(dtype)) % 16 == 0, SEGK_EALIGN, "conv_fwd: output pointer/ld misaligned");

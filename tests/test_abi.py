@@ -77,6 +77,9 @@ def test_argument_validation_needs_no_gpu():
         _lib.call("segk_linear_bwd", 16, 16, None, 4, 8, 8, None, 16, None, 0, 0, None)
     with pytest.raises(_lib.SegkError, match="SEGK_E"):
         _lib.call("segk_rows_mean_fwd", BF16, 16, 12, 2, 4, 12, 16, 0, None)     # 12 channels: not a multiple of 8
+    # the forward convolution packs (pixel index << 3) into 32 bits: 2^28 pixels and more per launch are refused, not mis-addressed
+    with pytest.raises(_lib.SegkError, match="2\\^28"):
+        _lib.call("segk_conv_fwd", BF16, 9, 16, 64, 64, None, 0, 0, 1 << 12, 256, 256, 16, 64, None, 16, 64, None, 0, 0, None, 0, 0, None, 0, 0, None)
     assert _lib.query("segk_norm_bwd_finish_workspace", 4096, 64) >= 2 * 64 * 4
     assert _lib.query("segk_conv_first_stat_rows", 32, 384, 384) > 0
 
