@@ -1381,8 +1381,8 @@ static int conv_fwd_impl(int dtype, int taps, const void* x0, int64_t ld0, int64
                          float* stat_partials, int flags, const NormBwdSums& nb, int dev, void* stream) {
     if (int rc = check_segments("conv_fwd", dtype, x0, ld0, C0, x1, ld1, C1)) return rc;
     SEGK_REQUIRE(!y1 || (split > 0 && split < Cout && split % 8 == 0 && ldy >= split && ldy1 >= Cout - split && aligned16(y1) &&
-                         (ldy1 * esize(dtype)) % 16 == 0 && !mask),
-                 SEGK_ESHAPE, "conv_fwd: second output needs 0 < split < Cout, split a multiple of 8, aligned y1, and no mask");
+                         (ldy1 * esize(dtype)) % 16 == 0 && (!mask || mask_channels <= split)),
+                 SEGK_ESHAPE, "conv_fwd: second output needs 0 < split < Cout, split a multiple of 8, aligned y1, and a mask (if any) within the first output");
     SEGK_REQUIRE(taps == 1 || taps == 9, SEGK_ESHAPE, "conv_fwd: taps must be 1 or 9");
     // the halo tables pack (pixel index << 3 | slot) into a signed 32-bit register
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 28), SEGK_ESHAPE, "conv_fwd: bad N/H/W (at most 2^28 - 1 pixels per launch)");

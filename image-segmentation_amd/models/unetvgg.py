@@ -14,6 +14,8 @@ skip concatenations of :99-103 written in place into shared NHWC buffers.
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn.functional as F
 from torch import nn
@@ -25,6 +27,7 @@ from segk.ops import Act
 # VGG configuration D: first feature index and conv widths of the five encoder stages; stages 2-5 start
 # with the 2x2 max pool that precedes them in torchvision's `features` list, whose numbering the
 # reference keeps by slicing that list (unetvgg.py:72-76).
+_INPLACE_CONCAT = bool(os.environ.get("SEGK_INPLACE_CONCAT"))   # experiment: [decoder output | skip] as slices of one buffer
 _ENCODER = ((0, (64, 64)), (6, (128, 128)), (13, (256, 256, 256)), (23, (512, 512, 512)), (33, (512, 512, 512)))
 # decoder blocks: name -> (in, mid, out); `in` = previous decoder output + skip width
 _DECODER = OrderedDict(center=(512, 512, 256), dec5=(768, 512, 256), dec4=(768, 512, 256), dec3=(512, 256, 64),
@@ -114,9 +117,12 @@ class _UNetVggBase(SegkNet):
         N, _, H, W = x.shape
         if H % 32 or W % 32:
             raise RuntimeError(f"UNetVgg needs H and W divisible by 32 (five 2x2 pools), got {H}x{W}")
-        # concat buffers of models/unetvgg.py:99-103: [decoder output | encoder skip], written in place
-        widths = {k: (_DECODER[f"dec{k + 1}" if k < 5 else "center"][2], _ENCODER[k - 1][1][-1]) for k in range(1, 6)}
-        cat = {k: rt.new(N, H >> (k - 1), W >> (k - 1), sum(widths[k])).buf for k in range(1, 6)}
+        if _INPLACE_CONCAT:
+            widths = {k: (_DECODER[f"dec{k + 1}" if k < 5 else "center"][2], _ENCODER[k - 1][1][-1]) for k in range(1, 6)}
+            cat = {k: rt.new(N, H >> (k - 1), W >> (k - 1), sum(widths[k])).buf for k in range(1, 6)}
+        # torch.cat of models/unetvgg.py:99-103: never materialised.  The decoder output and the encoder skip stay two
+        # tensors of their own (every producer writes whole, line-aligned pixels) and the convolution that reads the
+        # concatenation takes them as its two input segments; its data gradient writes each segment's gradient tensor.
         if hasattr(self, "conv0"):
             v = rt.conv_first(x, "conv0.weight", "conv0.bias")          # 3 channels stored as 8
         else:
@@ -134,16 +140,23 @@ class _UNetVggBase(SegkNet):
                 else:
                     y = rt.conv(v, wn + ".weight", wn + ".bias", bias_grad_zero=self.training, stats=True)
                 if j == len(stage_widths) - 1:   # skip tensor (second slice of the concat buffer) + pool for the next stage
-                    v, pooled = rt.bn_relu(y, bn_, out=Act(cat[k], widths[k][0], widths[k][1]), pool=True)
+                    v, pooled = rt.bn_relu(y, bn_, out=Act(cat[k], widths[k][0], widths[k][1]) if _INPLACE_CONCAT else None, pool=True)
                 else:
                     v = rt.bn_relu(y, bn_, one_reader=True)        # read by the stage's next convolution only
                 idx += 3
             skips[k] = v
-        d = self.center[1].emit(rt, "center.1.", pooled, out=Act(cat[5], 0, widths[5][0]))
+        if _INPLACE_CONCAT:
+            d = self.center[1].emit(rt, "center.1.", pooled, out=Act(cat[5], 0, widths[5][0]))
+            for k in (5, 4, 3, 2):
+                block = getattr(self, f"dec{k}")
+                d = block.emit(rt, f"dec{k}.", [d, skips[k]], out=Act(cat[k - 1], 0, widths[k - 1][0]))
+            e = rt.conv([d, skips[1]], "dec1.0.weight", "dec1.0.bias", relu=True)
+            return rt.head(e, "final.weight", "final.bias")
+        d = self.center[1].emit(rt, "center.1.", pooled)
         for k in (5, 4, 3, 2):
             block = getattr(self, f"dec{k}")
-            d = block.emit(rt, f"dec{k}.", [d, skips[k]], out=Act(cat[k - 1], 0, widths[k - 1][0]))
-        e = rt.conv([d, skips[1]], "dec1.0.weight", "dec1.0.bias", relu=True)
+            d = block.emit(rt, f"dec{k}.", (d, skips[k]))
+        e = rt.conv((d, skips[1]), "dec1.0.weight", "dec1.0.bias", relu=True)
         return rt.head(e, "final.weight", "final.bias")
 
 

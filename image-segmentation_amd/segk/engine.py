@@ -432,8 +432,9 @@ class Runtime:
             return
         # two segments: the kernel writes each segment's gradient straight into its own buffer
         (act0, mem0), (act1, mem1) = segs
-        assert mask_of(mem0) is None and mask_of(mem1) is None
-        ops.conv_fwd(dy, wb, Cin, (self.grad_of(act0), self.grad_of(act1)), taps=taps, accumulate=state(mem0), accumulate1=state(mem1))
+        assert mask_of(mem1) is None, "a tensor whose ReLU backward is deferred must be (in) the first segment"
+        ops.conv_fwd(dy, wb, Cin, (self.grad_of(act0), self.grad_of(act1)), taps=taps, mask=mask_of(mem0), accumulate=state(mem0),
+                     accumulate1=state(mem1))
         for m in mem0 + mem1:
             m.ready = True
 

@@ -178,7 +178,8 @@ int segk_conv_pack_batch(int dtype, const segk_pack_desc* descs_dev, int64_t n, 
  * where mask<=0: the ReLU backward of the producer(s) of those channels, fused into the data gradient.
  * flags bit1: accumulate into y (y += result) instead of overwriting.
  * y1 (optional): second destination -- output channels [split, Cout) are written to y1[..., c - split] (flags
- * bit2: accumulated there); the data gradient of a two-segment input lands directly in both segments' buffers.  */
+ * bit2: accumulated there); the data gradient of a two-segment input lands directly in both segments' buffers
+ * (a mask then has to lie within the first destination: mask_channels <= split).  */
 int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, const void* x1, int64_t ld1,
                   int64_t C1, int64_t N, int64_t H, int64_t W, const void* w_packed, int64_t Cout,
                   const float* bias, void* y, int64_t ldy, void* y1, int64_t ldy1, int64_t split, const void* mask,
