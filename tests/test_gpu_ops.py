@@ -159,6 +159,14 @@ def test_conv_two_segments(dtype):
     report("conv_dgrad_2dst_a", from_act(d0), ref_dx[:, :C0], **TOL[dtype])
     report("conv_dgrad_2dst_b", from_act(d1), ref_dx[:, C0:] + 1.0, **TOL[dtype])
     assert float(d0.buf[..., :8].float().abs().max()) == 0.0
+    # two destinations with the ReLU mask of the first segment's producer (a mask has to lie within the first destination)
+    mask = rnd((N, C0, H, W), dtype, 15)
+    m0, m1 = ops.Act.empty(N, H, W, C0, dtype, "cuda"), ops.Act.empty(N, H, W, C1, dtype, "cuda")
+    ops.conv_fwd(dya, wb, C0 + C1, (m0, m1), mask=to_act(mask, dtype))
+    report("conv_dgrad_2dst_masked_a", from_act(m0), ref_dx[:, :C0] * (mask > 0), **TOL[dtype])
+    report("conv_dgrad_2dst_masked_b", from_act(m1), ref_dx[:, C0:], **TOL[dtype])
+    with pytest.raises(Exception, match="within the first output"):
+        ops.conv_fwd(dya, wb, C0 + C1, (m0, m1), mask=ops.Act.empty(N, H, W, C0 + 8, dtype, "cuda"))
     dw = torch.empty_like(w, device="cuda")
     ops.conv_wgrad((a0, a1), dya, dw)
     ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, dy.double(), padding=1).float()
