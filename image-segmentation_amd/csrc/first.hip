@@ -36,14 +36,32 @@ struct FirstArgs {
     int64_t ldy;
     float* stat_part;      // optional [N * tiles * 4][2][Cout]
     int N, Cin, H, W, Cout, tiles_x, tiles_y, relu;
+    // recomputing modes (the convolution is followed by BatchNorm + ReLU and its output is never stored):
+    const float* nstats = nullptr;   // [Cout][2] mean, 1/std
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    const float* red = nullptr;      // [Cout][2] the norm backward's two sums
+    float inv_m = 0.f;               // 1 / (N*H*W)
+    const bf16* g = nullptr;         // gradient of relu(norm(conv(x))), NHWC
+    int64_t ldg = 0;
 };
+
+// What the kernel does with the convolution's (fp32, never rounded) output z = conv(x) + bias:
+//   kStore      store z (and, optionally, the per-wave statistics of the stored values)
+//   kStatsOnly  per-wave sum and sum of squares of z, nothing stored
+//   kNormRelu   store relu(norm(z))
+//   kBwdSums    with g = dL/d relu(norm(z)): per-wave sums of g*[pre > 0] and g*[pre > 0]*zhat
+//   kBwdDz      store dL/dz = gamma*rstd*(g*[pre > 0] - s1/M - zhat*s2/M)
+// The last four recompute z from the image (a few MFMAs per tile) instead of reading a stored copy: the image is
+// 1-3 channels, z is 64.
+enum FirstMode { kStore = 0, kStatsOnly = 1, kNormRelu = 2, kBwdSums = 3, kBwdDz = 4 };
 
 // NCT = Cout / 16 output-channel tiles (2 or 4); CIN input channels.  A workgroup walks kTilesPerWg vertically adjacent
 // 8 x 64 tiles: the weight fragments and the per-lane gather offsets are set up once, and the next tile's image values
 // are fetched into registers while the current tile is multiplied and stored.
 constexpr int kTilesPerWg = 6;
 
-template <int NCT, int CIN>
+template <int NCT, int CIN, int MODE = kStore>
 __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const FirstArgs a) {
     constexpr int PER_C = (kFTH + 2) * (kFTW + 2), NVAL = CIN * PER_C;
     constexpr int NLD = (NVAL + kFirstThreads - 1) / kFirstThreads;       // staged values per thread
@@ -127,6 +145,24 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
         }
     }
     if (tid == 0) img[kZeroWord] = 0.f;
+    // per-channel constants of the norm for this lane's channels, written exactly as the streaming norm kernels write them
+    constexpr bool kNorm = MODE >= kNormRelu;
+    constexpr bool kBwd = MODE == kBwdSums || MODE == kBwdDz;
+    float n_sc[kNorm ? NCT / 2 : 1][8], n_sh[kNorm ? NCT / 2 : 1][8], n_mean[kBwd ? NCT / 2 : 1][8], n_rstd[kBwd ? NCT / 2 : 1][8];
+    float n_m1[MODE == kBwdDz ? NCT / 2 : 1][8], n_m2[MODE == kBwdDz ? NCT / 2 : 1][8];
+    if constexpr (kNorm) {
+#pragma unroll
+        for (int k2 = 0; k2 < NCT / 2; ++k2)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int c = 32 * k2 + 8 * g + r;
+                const float mean = a.nstats[2 * c], rstd = a.nstats[2 * c + 1];
+                n_sc[k2][r] = rstd * (a.gamma ? a.gamma[c] : 1.f);
+                n_sh[k2][r] = (a.beta ? a.beta[c] : 0.f) - mean * n_sc[k2][r];
+                if constexpr (kBwd) { n_mean[k2][r] = mean; n_rstd[k2][r] = rstd; }
+                if constexpr (MODE == kBwdDz) { n_m1[k2][r] = a.red[2 * c] * a.inv_m; n_m2[k2][r] = a.red[2 * c + 1] * a.inv_m; }
+            }
+    }
 
     const int xx = x0 + 16 * wave + l15;
     for (int ty = ty_lo; ty < ty_hi; ++ty) {
@@ -143,16 +179,18 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
         for (int k2 = 0; k2 < NCT / 2; ++k2)
 #pragma unroll
             for (int r = 0; r < 8; ++r) ssum[k2][r] = ssq[k2][r] = 0.f;
+        // rows per pass: four, or two where the backward modes' per-channel constants need the registers
+        constexpr int RP = kBwd ? 2 : kFTH / 2;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-            f32x4 acc[NCT][kFTH / 2];
+        for (int half = 0; half < kFTH / RP; ++half) {
+            f32x4 acc[NCT][RP];
 #pragma unroll
             for (int t = 0; t < NCT; ++t)
 #pragma unroll
-                for (int j = 0; j < kFTH / 2; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < RP; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < kFTH / 2; ++j) {
-                const int row = half * (kFTH / 2) + j;
+            for (int j = 0; j < RP; ++j) {
+                const int row = half * RP + j;
                 bf16x8 pb;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) pb[e] = (bf16)img[off[e] + (off[e] == kZeroWord ? 0 : row * kFLW)];
@@ -161,32 +199,54 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
             }
             // row by row, both 32-channel halves of a pixel back to back: the 128 bytes of a pixel leave together
 #pragma unroll
-            for (int j = 0; j < kFTH / 2; ++j) {
-                const int yy = y0 + half * (kFTH / 2) + j;
+            for (int j = 0; j < RP; ++j) {
+                const int yy = y0 + half * RP + j;
                 if (yy >= a.H || xx >= a.W) continue;
-                bf16* dst = a.y + (((int64_t)n * a.H + yy) * a.W + xx) * a.ldy + 8 * g;
+                const int64_t pix = ((int64_t)n * a.H + yy) * a.W + xx;
+                bf16* dst = a.y + pix * a.ldy + 8 * g;
 #pragma unroll
                 for (int k2 = 0; k2 < NCT / 2; ++k2) {
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e] + bv[k2][e]; v[4 + e] = acc[2 * k2 + 1][j][e] + bv[k2][4 + e]; }
-                    if (a.relu) {
+                    if constexpr (MODE == kStore) {
+                        if (a.relu) {
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
-                    }
-                    Elem<bf16>::store8(dst + 32 * k2, v);
-                    if (a.stat_part) {
+                            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        Elem<bf16>::store8(dst + 32 * k2, v);
+                        if (a.stat_part) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const float q = (float)(bf16)v[r];
+                                ssum[k2][r] += q;
+                                ssq[k2][r] += q * q;
+                            }
+                        }
+                    } else if constexpr (MODE == kStatsOnly) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { ssum[k2][r] += v[r]; ssq[k2][r] += v[r] * v[r]; }
+                    } else if constexpr (MODE == kNormRelu) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r] * n_sc[k2][r] + n_sh[k2][r], 0.f);
+                        Elem<bf16>::store8(dst + 32 * k2, v);
+                    } else {
+                        float gr[8];
+                        Elem<bf16>::load8(a.g + pix * a.ldg + 32 * k2 + 8 * g, gr);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
-                            const float q = (float)(bf16)v[r];
-                            ssum[k2][r] += q;
-                            ssq[k2][r] += q * q;
+                            const float pre = v[r] * n_sc[k2][r] + n_sh[k2][r];
+                            const float zh = (v[r] - n_mean[k2][r]) * n_rstd[k2][r];
+                            const float gg = pre > 0.f ? gr[r] : 0.f;
+                            if constexpr (MODE == kBwdSums) { ssum[k2][r] += gg; ssq[k2][r] += gg * zh; }
+                            else v[r] = n_sc[k2][r] * (gg - n_m1[k2][r] - zh * n_m2[k2][r]);
                         }
+                        if constexpr (MODE == kBwdDz) Elem<bf16>::store8(dst + 32 * k2, v);
                     }
                 }
             }
         }
-        if (a.stat_part) {
+        if (a.stat_part && (MODE == kStore || MODE == kStatsOnly || MODE == kBwdSums)) {
 #pragma unroll
             for (int k2 = 0; k2 < NCT / 2; ++k2) {
                 const int co = 32 * k2 + 8 * g;
@@ -205,11 +265,11 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
     }
 }
 
-template <int NCT>
+template <int NCT, int MODE = kStore>
 static void launch_first(const FirstArgs& a, unsigned grid, hipStream_t st) {
-    if (a.Cin == 1) hipLaunchKernelGGL((conv_first_fwd_kernel<NCT, 1>), dim3(grid), dim3(kFirstThreads), 0, st, a);
-    else if (a.Cin == 2) hipLaunchKernelGGL((conv_first_fwd_kernel<NCT, 2>), dim3(grid), dim3(kFirstThreads), 0, st, a);
-    else hipLaunchKernelGGL((conv_first_fwd_kernel<NCT, 3>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    if (a.Cin == 1) hipLaunchKernelGGL((conv_first_fwd_kernel<NCT, 1, MODE>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    else if (a.Cin == 2) hipLaunchKernelGGL((conv_first_fwd_kernel<NCT, 2, MODE>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    else hipLaunchKernelGGL((conv_first_fwd_kernel<NCT, 3, MODE>), dim3(grid), dim3(kFirstThreads), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -443,6 +503,46 @@ extern "C" int segk_conv_first_fwd(const float* x, int64_t N, int64_t Cin, int64
     SEGK_REQUIRE(grid < (1ll << 31), SEGK_ESHAPE, "conv_first_fwd: grid too large");
     if (Cout == 64) launch_first<4>(a, (unsigned)grid, (hipStream_t)stream);
     else launch_first<2>(a, (unsigned)grid, (hipStream_t)stream);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
+// The first convolution followed by BatchNorm2d + ReLU (models/unetvgg.py:72 conv1.0-2; models/unetplusplus.py:45 conv0_0.conv1/bn1)
+// without ever storing the convolution's output: mode 1 = statistics partials of z = conv(x) + bias ([segk_conv_first_stat_rows][2][64],
+// for segk_norm_stats_finalize), 2 = out <- relu(norm(z)), 3 = partials of the norm backward's two sums from g = dL/d relu(norm(z))
+// (for segk_norm_bwd_sums_finalize), 4 = out <- dL/dz.  Every mode recomputes z from the 1-3 channel image.
+extern "C" int segk_conv_first_norm(int mode, const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const float* w,
+                                    const float* bias, int64_t Cout, const float* stats, const float* gamma, const float* beta,
+                                    const float* red, const void* g, int64_t ldg, void* out, int64_t ld_out, float* partials, int dev,
+                                    void* stream) {
+    SEGK_REQUIRE(mode >= kStatsOnly && mode <= kBwdDz, SEGK_EINVAL, "conv_first_norm: mode %d (1..4)", mode);
+    SEGK_REQUIRE(x && w, SEGK_EINVAL, "conv_first_norm: null pointer");
+    SEGK_REQUIRE(Cin >= 1 && Cin <= kFMaxCin, SEGK_ESHAPE, "conv_first_norm: %lld input channels (1..3)", (long long)Cin);
+    SEGK_REQUIRE(Cout == 64, SEGK_ESHAPE, "conv_first_norm: %lld output channels (64)", (long long)Cout);
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_first_norm: bad N/H/W");
+    const bool sums = mode == kStatsOnly || mode == kBwdSums, store = mode == kNormRelu || mode == kBwdDz;
+    SEGK_REQUIRE(!sums || (partials && aligned16(partials)), SEGK_EINVAL, "conv_first_norm: modes 1 and 3 need a 16-byte aligned partials buffer");
+    SEGK_REQUIRE(!store || (out && ld_out >= Cout && aligned16(out) && (ld_out * 2) % 16 == 0), SEGK_EALIGN,
+                 "conv_first_norm: modes 2 and 4 need an aligned bf16 output with ld >= Cout");
+    SEGK_REQUIRE(mode == kStatsOnly || stats, SEGK_EINVAL, "conv_first_norm: modes 2-4 need the statistics vector");
+    SEGK_REQUIRE(mode < kBwdSums || (g && ldg >= Cout && aligned16(g) && (ldg * 2) % 16 == 0), SEGK_EALIGN,
+                 "conv_first_norm: modes 3 and 4 need an aligned bf16 gradient with ld >= Cout");
+    SEGK_REQUIRE(mode != kBwdDz || red, SEGK_EINVAL, "conv_first_norm: mode 4 needs the reduced sums");
+    SEGK_USE_DEVICE(dev);
+    FirstArgs a;
+    a.x = x; a.w = w; a.bias = bias; a.y = (bf16*)out; a.ldy = ld_out; a.stat_part = sums ? partials : nullptr;
+    a.N = (int)N; a.Cin = (int)Cin; a.H = (int)H; a.W = (int)W; a.Cout = (int)Cout;
+    a.tiles_x = (int)((W + kFTW - 1) / kFTW); a.tiles_y = (int)((H + kFTH - 1) / kFTH);
+    a.relu = 0;
+    a.nstats = stats; a.gamma = gamma; a.beta = beta; a.red = red; a.inv_m = 1.f / (float)(N * H * W);
+    a.g = (const bf16*)g; a.ldg = ldg;
+    const int64_t grid = N * a.tiles_x * ((a.tiles_y + kTilesPerWg - 1) / kTilesPerWg);
+    SEGK_REQUIRE(grid < (1ll << 31), SEGK_ESHAPE, "conv_first_norm: grid too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == kStatsOnly) launch_first<4, kStatsOnly>(a, (unsigned)grid, st);
+    else if (mode == kNormRelu) launch_first<4, kNormRelu>(a, (unsigned)grid, st);
+    else if (mode == kBwdSums) launch_first<4, kBwdSums>(a, (unsigned)grid, st);
+    else launch_first<4, kBwdDz>(a, (unsigned)grid, st);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

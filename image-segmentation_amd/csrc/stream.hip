@@ -1532,6 +1532,35 @@ extern "C" int segk_norm_bwd_finish(int dtype, const float* partials, int64_t ro
     return SEGK_OK;
 }
 
+// The reduction half of segk_norm_bwd_finish on its own: partial rows [rows][2][C] of (sum g, sum g*xhat) -> red[C][2],
+// dgamma, dbeta.  For a producer of the partials that also computes dx itself (segk_conv_first_norm, modes 3 and 4).
+// workspace: segk_norm_stats_finalize_workspace(1, rows, C) bytes.
+extern "C" int segk_norm_bwd_sums_finalize(const float* partials, int64_t rows, int64_t C, float* red, float* dgamma, float* dbeta,
+                                           int flags, void* workspace, size_t workspace_bytes, int dev, void* stream) {
+    if (int rc = check_norm_c("norm_bwd_sums_finalize", C)) return rc;
+    SEGK_REQUIRE(partials && aligned16(partials) && rows > 0 && rows < (1ll << 31) && red, SEGK_EINVAL, "norm_bwd_sums_finalize: bad arguments");
+    SEGK_REQUIRE(2 * C / 8 <= kThreads, SEGK_ESHAPE, "norm_bwd_sums_finalize: at most 1024 channels");
+    SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "norm_bwd_sums_finalize: dgamma/dbeta come in pairs");
+    SEGK_REQUIRE(rows <= 128 || (workspace && workspace_bytes >= segk_norm_stats_finalize_workspace(1, rows, C)), SEGK_EWORKSPACE,
+                 "norm_bwd_sums_finalize: workspace too small");
+    SEGK_USE_DEVICE(dev);
+    hipStream_t st = (hipStream_t)stream;
+    const int accumulate = (flags >> 1) & 1;
+    if (rows <= 128) {
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, 1), dim3(kThreads), 0, st, partials, (int)rows, (int)C, red, dgamma,
+                           dbeta, accumulate, (int64_t)(2 * C));
+    } else {
+        const int bpg = stats_bpg(1, rows, 2 * C);
+        hipLaunchKernelGGL((stats_partial_kernel<float, 1>), dim3(bpg, 1), dim3(kThreads), 0, st, partials, 2 * C, rows, (int)(2 * C), bpg,
+                           (float*)workspace, (float*)nullptr);
+        SEGK_LAUNCH_CHECK();
+        hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, 1), dim3(kThreads), 0, st, (const float*)workspace, bpg, (int)C, red,
+                           dgamma, dbeta, accumulate, (int64_t)(4 * C));
+    }
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
+}
+
 extern "C" int segk_norm_pool_apply(int dtype, const void* x, int64_t ldx, int64_t N, int64_t H, int64_t W, int64_t C,
                                     const float* stats, const float* gamma, const float* beta, void* y, int64_t ldy, void* pool,
                                     int64_t ld_pool, int dev, void* stream) {

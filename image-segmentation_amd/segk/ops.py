@@ -143,6 +143,34 @@ def conv_first_fwd(x, w, bias, out, relu=False, want_stats=False):
     return part
 
 
+def conv_first_norm(mode, x, w, bias, stats=None, gamma=None, beta=None, red=None, g=None, out=None):
+    """The first convolution fused with the BatchNorm2d + ReLU behind it, its output recomputed instead of stored
+    (segk_conv_first_norm): mode 1 -> statistics partials, 2 -> out = relu(norm(conv)), 3 -> partials of the norm
+    backward's sums from g, 4 -> out = gradient of the convolution's output."""
+    N, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    x = x.contiguous().float()
+    part = None
+    if mode in (1, 3):
+        part = torch.empty(query("segk_conv_first_stat_rows", N, H, W), 2, Cout, dtype=torch.float32, device=x.device)
+    dev, st = _env(x)
+    with _Timed("conv_fwd", 2.0 * N * H * W * Cout * 32, "first layer"):
+        call("segk_conv_first_norm", mode, x.data_ptr(), N, Cin, H, W, w.detach().contiguous().data_ptr(), _p(bias), Cout, _p(stats),
+             _p(gamma), _p(beta), _p(red), g.ptr if g is not None else None, g.ld if g is not None else 0,
+             out.ptr if out is not None else None, out.ld if out is not None else 0, _p(part), dev, st)
+    return part
+
+
+def norm_bwd_sums_finalize(partials, red, dgamma=None, dbeta=None, accumulate=False):
+    """Partial rows [rows][2][C] of the norm backward's two sums -> red [C][2] (+ dgamma, dbeta)."""
+    rows, _, C = partials.shape
+    dev, st = _env(partials)
+    ws = workspace(query("segk_norm_stats_finalize_workspace", 1, rows, C), partials.device)
+    call("segk_norm_bwd_sums_finalize", partials.data_ptr(), rows, C, red.data_ptr(), _p(dgamma), _p(dbeta), ACCUM if accumulate else 0,
+         ws.data_ptr(), ws.numel(), dev, st)
+    return red
+
+
 def conv_first_wgrad(x, dy, dw, accumulate=False):
     """dw (fp32 [64, Cin, 3, 3]) = weight gradient of the first convolution from the fp32 NCHW image x and dy (bf16 Act)."""
     N, Cin, H, W = x.shape

@@ -125,6 +125,22 @@ int segk_conv_first_fwd(const float* x, int64_t N, int64_t Cin, int64_t H, int64
                         int64_t Cout, void* y, int y_dtype, int64_t ldy, float* stat_partials, int flags, int dev,
                         void* stream);
 
+/* The first convolution together with the BatchNorm2d + ReLU behind it, WITHOUT storing the convolution's output
+ * z = bias + conv3x3(x, w): every mode recomputes z from the 1..3-channel image (a few matrix steps per tile) instead of
+ * moving a 64-channel tensor.  Cout = 64, bf16 NHWC tensors, batch statistics.
+ *   mode 1: partials <- per-wave sum and sum of squares of z (fp32 [segk_conv_first_stat_rows(N,H,W)][2][64];
+ *           segk_norm_stats_finalize turns them into `stats` and updates the running buffers)
+ *   mode 2: out <- relu(gamma * (z - mean) * rstd + beta)
+ *   mode 3: partials <- per-wave sums of g*[pre > 0] and g*[pre > 0]*zhat for g = dL/d out (segk_norm_bwd_sums_finalize
+ *           reduces them to `red`, dgamma, dbeta)
+ *   mode 4: out <- dL/dz = gamma*rstd*(g*[pre > 0] - red[c][0]/M - zhat*red[c][1]/M), the input of segk_conv_first_wgrad
+ * replaces: features[0..2] of models/unetvgg.py:72 (Conv2d(3,64) -> BatchNorm2d -> ReLU) and conv1/bn1/activation of
+ *           models/unetplusplus.py:11-12,16-19 for conv0_0, forward and backward.                                   */
+int segk_conv_first_norm(int mode, const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const float* w,
+                         const float* bias, int64_t Cout, const float* stats, const float* gamma, const float* beta,
+                         const float* red, const void* g, int64_t ldg, void* out, int64_t ld_out, float* partials, int dev,
+                         void* stream);
+
 /* Weight gradient of that first convolution, again straight from the image: dw (fp32, the module's [64, Cin, 3, 3]
  * layout) = sum over pixels of dy (bf16 NHWC, 64 channels) x the 3x3 neighbourhood of x; per-workgroup partial blocks
  * are added in fixed order (deterministic).  flags bit1: dw += result.
@@ -367,6 +383,13 @@ int segk_norm_bwd_finish(int dtype, const float* partials, int64_t rows, const v
                          int64_t ldx, int64_t M, int64_t C, const float* stats, const float* gamma, const float* beta,
                          int flags, void* dx, int64_t ld_dx, float* dgamma, float* dbeta, void* workspace,
                          size_t workspace_bytes, int dev, void* stream);
+
+/* The reduction half of segk_norm_bwd_finish alone: partial rows [rows][2][C] of (sum g, sum g*xhat) -> red[C][2], dgamma,
+ * dbeta (flags bit1: accumulated), for a producer that computes dx itself (segk_conv_first_norm modes 3 and 4).
+ * workspace: segk_norm_stats_finalize_workspace(1, rows, C) bytes (none needed for rows <= 128).
+ * replaces: the per-channel sums of BatchNorm2d's backward (models/unetvgg.py:72 features[1]).                 */
+int segk_norm_bwd_sums_finalize(const float* partials, int64_t rows, int64_t C, float* red, float* dgamma, float* dbeta,
+                                int flags, void* workspace, size_t workspace_bytes, int dev, void* stream);
 
 /* BatchNorm (batch or running statistics in `stats`) + ReLU + the 2x2/stride-2 max pool behind it, one pass:
  * y = relu(norm(x)) [N,H,W,C] and pool = maxpool2x2(y) [N,H/2,W/2,C].

@@ -134,6 +134,52 @@ def test_conv_thin_layers_bf16(case):
     assert float(dx.buf[..., :8].float().abs().max()) == 0.0, "wrote outside the output slice"
 
 
+@pytest.mark.parametrize("cin", [1, 3])
+def test_first_conv_with_norm_recomputed(cin):
+    """Conv2d(cin, 64) -> BatchNorm2d (batch statistics) -> ReLU, forward and backward, with the convolution's output
+    recomputed from the image in every pass instead of stored (segk_conv_first_norm modes 1-4)."""
+    from segk import ops
+    from util import rel_l2
+    N, H, W, C = 2, 24, 80, 64                      # W: one full 64-column tile and a partial one
+    bf = torch.bfloat16
+    x = rnd((N, cin, H, W), bf, 21)
+    w = rnd((C, cin, 3, 3), bf, 22, scale=0.4)
+    b = rnd((C,), torch.float32, 23, scale=0.3)
+    gamma = 0.5 + torch.rand(C, generator=torch.Generator().manual_seed(24))
+    beta = rnd((C,), torch.float32, 25, scale=0.5)
+    g = rnd((N, C, H, W), bf, 26)
+    eps, M = 1e-5, N * H * W
+    # reference in double from the same bf16-representable operands
+    z = F.conv2d(x.double(), w.double(), b.double(), padding=1).requires_grad_(True)
+    gm, bt = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    mean, var = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+    zh = (z - mean[None, :, None, None]) / torch.sqrt(var + eps)[None, :, None, None]
+    a_ref = torch.relu(zh * gm[None, :, None, None] + bt[None, :, None, None])
+    (a_ref * g.double()).sum().backward()
+    xc, wc, bc, gc, btc = x.cuda(), w.cuda(), b.cuda(), gamma.cuda(), beta.cuda()
+    part = ops.conv_first_norm(1, xc, wc, bc)
+    stats = torch.empty(2 * C, device="cuda")
+    rmean, rvar = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    ops.norm_stats_from_partials(part, 1, M, eps, stats, rmean, rvar, 0.1)
+    st = stats.view(C, 2).cpu().double()
+    report("stem_mean", st[:, 0], mean.detach(), rtol=1e-4, atol=1e-5)
+    report("stem_rstd", st[:, 1], 1.0 / torch.sqrt(var.detach() + eps), rtol=1e-4, atol=1e-5)
+    report("stem_running_var", rvar.cpu(), 0.9 + 0.1 * var.detach() * M / (M - 1), rtol=1e-4, atol=1e-5)
+    out = ops.Act.empty(N, H, W, C, bf, "cuda")
+    ops.conv_first_norm(2, xc, wc, bc, stats=stats, gamma=gc, beta=btc, out=out)
+    report("stem_out", from_act(out), a_ref.detach(), **TOL[bf])
+    ga = to_act(g, bf, ld=C + 8)
+    part2 = ops.conv_first_norm(3, xc, wc, bc, stats=stats, gamma=gc, beta=btc, g=ga)
+    red = torch.empty(2 * C, device="cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.norm_bwd_sums_finalize(part2, red, dgamma=dg, dbeta=db)
+    assert rel_l2(dg.cpu(), gm.grad) < 2e-3 and rel_l2(db.cpu(), bt.grad) < 2e-3, (rel_l2(dg.cpu(), gm.grad), rel_l2(db.cpu(), bt.grad))
+    dz = ops.Act.empty(N, H, W, C, bf, "cuda")
+    ops.conv_first_norm(4, xc, wc, bc, stats=stats, gamma=gc, beta=btc, red=red, g=ga, out=dz)
+    assert rel_l2(from_act(dz), z.grad) < 1e-2, rel_l2(from_act(dz), z.grad)      # bf16 storage of dz: 4e-3
+    report("stem_dz", from_act(dz), z.grad, rtol=2e-2, atol=2e-2 * float(z.grad.abs().max()))
+
+
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
 def test_conv_two_segments(dtype):
     from segk import ops
