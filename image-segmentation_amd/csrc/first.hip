@@ -148,8 +148,11 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
     // per-channel constants of the norm for this lane's channels, written exactly as the streaming norm kernels write them
     constexpr bool kNorm = MODE >= kNormRelu;
     constexpr bool kBwd = MODE == kBwdSums || MODE == kBwdDz;
-    float n_sc[kNorm ? NCT / 2 : 1][8], n_sh[kNorm ? NCT / 2 : 1][8], n_mean[kBwd ? NCT / 2 : 1][8], n_rstd[kBwd ? NCT / 2 : 1][8];
-    float n_m1[MODE == kBwdDz ? NCT / 2 : 1][8], n_m2[MODE == kBwdDz ? NCT / 2 : 1][8];
+    // The backward modes keep as few constants live as the arithmetic allows (the registers go to the gradient vectors that
+    // are requested ahead of the matrix steps): the sums are taken of g and g*z and turned into sum g*zhat when the partial
+    // row is written; dz = sc*(g - m1 - zhat*m2) is evaluated as sc*g - n_a - n_b*z with n_b = sc*m2*rstd, n_a = sc*m1 - n_b*mean.
+    float n_sc[kNorm ? NCT / 2 : 1][8], n_sh[kNorm ? NCT / 2 : 1][8];
+    float n_a[MODE == kBwdDz ? NCT / 2 : 1][8], n_b[MODE == kBwdDz ? NCT / 2 : 1][8];
     if constexpr (kNorm) {
 #pragma unroll
         for (int k2 = 0; k2 < NCT / 2; ++k2)
@@ -159,8 +162,10 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
                 const float mean = a.nstats[2 * c], rstd = a.nstats[2 * c + 1];
                 n_sc[k2][r] = rstd * (a.gamma ? a.gamma[c] : 1.f);
                 n_sh[k2][r] = (a.beta ? a.beta[c] : 0.f) - mean * n_sc[k2][r];
-                if constexpr (kBwd) { n_mean[k2][r] = mean; n_rstd[k2][r] = rstd; }
-                if constexpr (MODE == kBwdDz) { n_m1[k2][r] = a.red[2 * c] * a.inv_m; n_m2[k2][r] = a.red[2 * c + 1] * a.inv_m; }
+                if constexpr (MODE == kBwdDz) {
+                    n_b[k2][r] = n_sc[k2][r] * (a.red[2 * c + 1] * a.inv_m) * rstd;
+                    n_a[k2][r] = n_sc[k2][r] * (a.red[2 * c] * a.inv_m) - n_b[k2][r] * mean;
+                }
             }
     }
 
@@ -188,6 +193,19 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
             for (int t = 0; t < NCT; ++t)
 #pragma unroll
                 for (int j = 0; j < RP; ++j) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // backward modes: this pass's gradient vectors are requested before the gathers and matrix steps that they wait behind
+            struct alignas(16) G8 { bf16 e[8]; };
+            G8 gq[kBwd ? RP : 1][kBwd ? NCT / 2 : 1];
+            if constexpr (kBwd) {
+#pragma unroll
+                for (int j = 0; j < RP; ++j) {
+                    const int yy = ty * kFTH + half * RP + j;
+                    if (yy >= a.H || xx >= a.W) continue;
+                    const bf16* gp = a.g + (((int64_t)n * a.H + yy) * a.W + xx) * a.ldg + 8 * g;
+#pragma unroll
+                    for (int k2 = 0; k2 < NCT / 2; ++k2) gq[j][k2] = *reinterpret_cast<const G8*>(gp + 32 * k2);
+                }
+            }
 #pragma unroll
             for (int j = 0; j < RP; ++j) {
                 const int row = half * RP + j;
@@ -231,15 +249,12 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
                         for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r] * n_sc[k2][r] + n_sh[k2][r], 0.f);
                         Elem<bf16>::store8(dst + 32 * k2, v);
                     } else {
-                        float gr[8];
-                        Elem<bf16>::load8(a.g + pix * a.ldg + 32 * k2 + 8 * g, gr);
 #pragma unroll
                         for (int r = 0; r < 8; ++r) {
                             const float pre = v[r] * n_sc[k2][r] + n_sh[k2][r];
-                            const float zh = (v[r] - n_mean[k2][r]) * n_rstd[k2][r];
-                            const float gg = pre > 0.f ? gr[r] : 0.f;
-                            if constexpr (MODE == kBwdSums) { ssum[k2][r] += gg; ssq[k2][r] += gg * zh; }
-                            else v[r] = n_sc[k2][r] * (gg - n_m1[k2][r] - zh * n_m2[k2][r]);
+                            const float gg = pre > 0.f ? (float)gq[j][k2].e[r] : 0.f;
+                            if constexpr (MODE == kBwdSums) { ssum[k2][r] += gg; ssq[k2][r] += gg * v[r]; }
+                            else v[r] = n_sc[k2][r] * gg - n_a[k2][r] - n_b[k2][r] * v[r];
                         }
                         if constexpr (MODE == kBwdDz) Elem<bf16>::store8(dst + 32 * k2, v);
                     }
@@ -252,6 +267,13 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_fwd_kernel(const 
                 const int co = 32 * k2 + 8 * g;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) { ssum[k2][r] = first_row16_sum(ssum[k2][r]); ssq[k2][r] = first_row16_sum(ssq[k2][r]); }
+                if constexpr (MODE == kBwdSums) {      // (sum g, sum g*z) -> (sum g, sum g*zhat)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        const float mean = a.nstats[2 * (co + r)], rstd = a.nstats[2 * (co + r) + 1];
+                        ssq[k2][r] = rstd * (ssq[k2][r] - mean * ssum[k2][r]);
+                    }
+                }
                 if (l15 == 0) {
                     const int64_t row = (((int64_t)n * a.tiles_y + ty) * a.tiles_x + tx) * 4 + wave;
                     float* dst = a.stat_part + row * 2 * a.Cout + co;
@@ -291,7 +313,22 @@ struct FirstWgradArgs {
     int64_t ld;
     float* slab;           // [workgroups][64][32]
     int N, Cin, H, W, tiles_x, tiles_y, ntiles;
+    // recomputing modes: dy is g = dL/d relu(norm(z)) with z = conv(x, w) + bias recomputed per tile
+    const float* w = nullptr;        // [64, Cin, 3, 3]
+    const float* bias = nullptr;
+    const float* nstats = nullptr;   // [64][2] mean, 1/std
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    const float* red = nullptr;      // [64][2] the norm backward's two sums (kWgDz)
+    float inv_m = 0.f;
+    float* part = nullptr;           // kWgSums: [workgroups * 4][2][64] partial rows of (sum g', sum g' * zhat)
 };
+
+// kWgPlain: dy is the gradient of the convolution's output.  kWgSums / kWgDz: dy is the gradient g of relu(norm(z)); the
+// workgroup recomputes z for its tile from the image halo it holds anyway (16 matrix steps per wave) and either reduces
+// the norm backward's two sums over its tiles (kWgSums, no weight gradient) or turns g into dL/dz IN the LDS stage,
+// where the weight gradient's transposing reads pick it up (kWgDz): dL/dz never exists in HBM.
+enum FirstWgMode { kWgPlain = 0, kWgSums = 1, kWgDz = 2 };
 
 __device__ const uint4 kFirstZero = {0u, 0u, 0u, 0u};
 
@@ -303,7 +340,7 @@ __device__ __forceinline__ void first_glds16(const char* src, unsigned lds_addr)
                  : "memory");
 }
 
-template <int CIN>
+template <int CIN, int MODE = kWgPlain>
 __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_wgrad_kernel(const FirstWgradArgs a) {
     constexpr int KMAX = 9 * CIN;
     constexpr int PER_C = (kGTH + 2) * (kGTW + 2), NVAL = CIN * PER_C;
@@ -398,6 +435,61 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_wgrad_kernel(cons
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc[kt][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // ---- recomputing modes: forward operands of this wave's 4 x 16 pixels, and the norm's constants of this lane's channels ----
+    constexpr bool kRe = MODE != kWgPlain;
+    bf16x8 wa[kRe ? 4 : 1];                 // weights, rows = output channels in MFMA order, K = patch index 8g .. 8g+7
+    int foff[kRe ? 8 : 1];                  // image words of the patch values of pixel (row 4*half, column 16*strip + l15)
+    float n_sc[kRe ? 2 : 1][8], n_sh[kRe ? 2 : 1][8];       // pre = acc * sc + sh (the convolution's bias folded into sh)
+    float n_a[MODE == kWgDz ? 2 : 1][8], n_b[MODE == kWgDz ? 2 : 1][8];   // dz = sc*g' - n_a - n_b*acc
+    float s1[MODE == kWgSums ? 2 : 1][8], s2[MODE == kWgSums ? 2 : 1][8];
+    unsigned gadr[kRe ? 2 : 1];             // LDS byte offset (stage 0) of this lane's 16-byte channel slot, row 4*half, k2 = 0, 1
+    if constexpr (kRe) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int co = first_row_channel(t * 16 + l15);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * g + e;
+                float v = 0.f;
+                if (k < KMAX) {
+                    const int tap = k / CIN, c = k - tap * CIN;
+                    v = a.w[((int64_t)co * CIN + c) * 9 + tap];
+                }
+                wa[t][e] = (bf16)v;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 8 * g + e;
+            if (k < KMAX) {
+                const int tap = k / CIN, c = k - tap * CIN;
+                foff[e] = (c * (kGTH + 2) + 4 * half + tap / 3) * kGLW + tap % 3 + 16 * strip + l15;
+            } else {
+                foff[e] = -1;
+            }
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const int c = 32 * k2 + 8 * g + r;
+                const float mean = a.nstats[2 * c], rstd = a.nstats[2 * c + 1], bs = a.bias ? a.bias[c] : 0.f;
+                const float sc = rstd * (a.gamma ? a.gamma[c] : 1.f);
+                n_sc[k2][r] = sc;
+                n_sh[k2][r] = (a.beta ? a.beta[c] : 0.f) - mean * sc + bs * sc;
+                if constexpr (MODE == kWgDz) {
+                    // zhat = (acc + bias - mean) * rstd ;  dz = sc*(g' - m1 - zhat*m2)
+                    const float m1 = a.red[2 * c] * a.inv_m, m2 = a.red[2 * c + 1] * a.inv_m;
+                    n_b[k2][r] = sc * m2 * rstd;
+                    n_a[k2][r] = sc * m1 + n_b[k2][r] * (bs - mean);
+                }
+                if constexpr (MODE == kWgSums) s1[k2][r] = s2[k2][r] = 0.f;
+            }
+            const int col = 16 * strip + l15;
+            gadr[k2] = ((4 * half) * kGTW + col) * 128 + (((4 * k2 + g) ^ swz(col)) << 4);
+        }
+    }
+
     const int first = blockIdx.x, stride = gridDim.x;
     float cur[NLD];
     if (first < a.ntiles) {
@@ -417,6 +509,46 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_wgrad_kernel(cons
             stage_dy(tn, st ^ 1);
             fetch(tn, cur);
         }
+        if constexpr (kRe) {
+            // z for this wave's 4 rows x 16 columns, then this lane's g vectors from the stage: sums, or dz written back in place
+            const Tile tc = decode(t);
+            char* const stage = smem + st * kGTileBytes;
+            const bool col_ok = tc.x0 + 16 * strip + l15 < a.W;
+#pragma unroll 1
+            for (int row = 0; row < 4; ++row) {         // one row at a time: the registers go to the constants and the sums
+                constexpr int j = 0;
+                f32x4 z[4][1];
+                {
+                    bf16x8 pb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pb[e] = (bf16)img[foff[e] >= 0 ? foff[e] + row * kGLW : IMG_WORDS];
+#pragma unroll
+                    for (int tt = 0; tt < 4; ++tt)
+                        z[tt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[tt], pb, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+                {
+                    const bool ok = col_ok && tc.y0 + 4 * half + row < a.H;
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) {
+                        struct alignas(16) G8 { bf16 e[8]; };
+                        G8* slot = reinterpret_cast<G8*>(stage + gadr[k2] + row * kGTW * 128);
+                        const G8 gv = *slot;
+                        G8 dz;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            const float zz = r < 4 ? z[2 * k2][j][r & 3] : z[2 * k2 + 1][j][r & 3];
+                            const float pre = zz * n_sc[k2][r] + n_sh[k2][r];
+                            const float gg = pre > 0.f ? (float)gv.e[r] : 0.f;
+                            if constexpr (MODE == kWgSums) { s1[k2][r] += gg; s2[k2][r] += gg * zz; }
+                            else dz.e[r] = (bf16)(ok ? n_sc[k2][r] * gg - n_a[k2][r] - n_b[k2][r] * zz : 0.f);
+                        }
+                        if constexpr (MODE == kWgDz) *slot = dz;
+                    }
+                }
+            }
+            if constexpr (MODE == kWgDz) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the wave reads back only what it wrote itself
+        }
+        if constexpr (MODE != kWgSums)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             // patch fragments: K = 8g + 4h + q  <->  pixel (row 2*ks + h, column 4g + q) of this wave's strip
@@ -440,6 +572,28 @@ __global__ __launch_bounds__(kFirstThreads, 2) void conv_first_wgrad_kernel(cons
                     acc[kt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[kt], __builtin_bit_cast(bf16x8, fb), acc[kt][ct], 0, 0, 0);
             }
         }
+    }
+    if constexpr (MODE == kWgSums) {
+        // one partial row per wave: (sum g', sum g'*zhat) with zhat = (acc + bias - mean) * rstd applied to the two raw sums
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const int co = 32 * k2 + 8 * g;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                s1[k2][r] = first_row16_sum(s1[k2][r]);
+                s2[k2][r] = first_row16_sum(s2[k2][r]);
+                const float mean = a.nstats[2 * (co + r)], rstd = a.nstats[2 * (co + r) + 1], bs = a.bias ? a.bias[co + r] : 0.f;
+                s2[k2][r] = rstd * (s2[k2][r] + (bs - mean) * s1[k2][r]);
+            }
+            if (l15 == 0) {
+                float* dst = a.part + ((int64_t)(blockIdx.x * 4 + wave) * 2) * 64 + co;
+                *reinterpret_cast<float4*>(dst) = make_float4(s1[k2][0], s1[k2][1], s1[k2][2], s1[k2][3]);
+                *reinterpret_cast<float4*>(dst + 4) = make_float4(s1[k2][4], s1[k2][5], s1[k2][6], s1[k2][7]);
+                *reinterpret_cast<float4*>(dst + 64) = make_float4(s2[k2][0], s2[k2][1], s2[k2][2], s2[k2][3]);
+                *reinterpret_cast<float4*>(dst + 64 + 4) = make_float4(s2[k2][4], s2[k2][5], s2[k2][6], s2[k2][7]);
+            }
+        }
+        return;
     }
     // ---- sum the four waves' blocks through LDS (the dy stages are free now), one slab per workgroup ----
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -553,6 +707,67 @@ extern "C" size_t segk_conv_first_wgrad_workspace(int64_t N, int64_t H, int64_t 
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     const int64_t ntiles = N * ((H + kGTH - 1) / kGTH) * ((W + kGTW - 1) / kGTW);
     return (size_t)first_wgrad_grid(ntiles) * 64 * 32 * sizeof(float);
+}
+
+// Backward of Conv2d(Cin, 64) -> BatchNorm2d (batch statistics) -> ReLU from g = dL/d(output), the image and the parameters:
+// two streaming passes over g.  Pass 1 recomputes z per tile and reduces the norm's two sums (-> dgamma, dbeta); pass 2
+// recomputes z again, turns g into dL/dz inside the LDS stage and multiplies it into the weight gradient.  Neither z nor
+// dL/dz is ever written to memory.
+static size_t first_norm_bwd_sections(int64_t N, int64_t H, int64_t W, size_t* part_off, size_t* red_off, size_t* fin_off) {
+    const int64_t ntiles = N * ((H + kGTH - 1) / kGTH) * ((W + kGTW - 1) / kGTW);
+    const size_t grid = (size_t)first_wgrad_grid(ntiles);
+    size_t off = align_up(grid * 64 * 32 * sizeof(float), 256);
+    *part_off = off; off += align_up(grid * 4 * 2 * 64 * sizeof(float), 256);
+    *red_off = off; off += 256 * sizeof(float);
+    *fin_off = off; off += align_up(segk_norm_stats_finalize_workspace(1, (int64_t)grid * 4, 64), 256);
+    return off;
+}
+
+extern "C" size_t segk_conv_first_norm_bwd_workspace(int64_t N, int64_t H, int64_t W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    size_t a, b, c;
+    return first_norm_bwd_sections(N, H, W, &a, &b, &c);
+}
+
+extern "C" int segk_conv_first_norm_bwd(const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const float* w, const float* bias,
+                                        const float* stats, const float* gamma, const float* beta, const void* g, int64_t ldg,
+                                        float* dw, float* dgamma, float* dbeta, int flags, void* workspace, size_t workspace_bytes,
+                                        int dev, void* stream) {
+    SEGK_REQUIRE(x && w && stats && g && dw && workspace, SEGK_EINVAL, "conv_first_norm_bwd: null pointer");
+    SEGK_REQUIRE(Cin >= 1 && Cin <= kFMaxCin, SEGK_ESHAPE, "conv_first_norm_bwd: %lld input channels (1..3)", (long long)Cin);
+    SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_first_norm_bwd: bad N/H/W");
+    SEGK_REQUIRE(ldg >= 64 && aligned16(g) && (ldg * 2) % 16 == 0, SEGK_EALIGN, "conv_first_norm_bwd: gradient pointer/ld misaligned or ld < 64");
+    SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "conv_first_norm_bwd: dgamma/dbeta come in pairs");
+    size_t part_off, red_off, fin_off;
+    const size_t need = first_norm_bwd_sections(N, H, W, &part_off, &red_off, &fin_off);
+    SEGK_REQUIRE(workspace_bytes >= need, SEGK_EWORKSPACE, "conv_first_norm_bwd: workspace too small");
+    SEGK_USE_DEVICE(dev);
+    FirstWgradArgs a;
+    a.x = x; a.dy = (const bf16*)g; a.ld = ldg; a.slab = (float*)workspace;
+    a.N = (int)N; a.Cin = (int)Cin; a.H = (int)H; a.W = (int)W;
+    a.tiles_x = (int)((W + kGTW - 1) / kGTW); a.tiles_y = (int)((H + kGTH - 1) / kGTH);
+    a.ntiles = (int)(N * a.tiles_x * a.tiles_y);
+    a.w = w; a.bias = bias; a.nstats = stats; a.gamma = gamma; a.beta = beta;
+    a.part = (float*)((char*)workspace + part_off);
+    float* red = (float*)((char*)workspace + red_off);
+    a.red = red; a.inv_m = 1.f / (float)(N * H * W);
+    const int grid = first_wgrad_grid(a.ntiles);
+    hipStream_t st = (hipStream_t)stream;
+    if (Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    else if (Cin == 2) hipLaunchKernelGGL((conv_first_wgrad_kernel<2, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    else hipLaunchKernelGGL((conv_first_wgrad_kernel<3, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    SEGK_LAUNCH_CHECK();
+    if (int rc = segk_norm_bwd_sums_finalize(a.part, (int64_t)grid * 4, 64, red, dgamma, dbeta, flags & 2, (char*)workspace + fin_off,
+                                             need - fin_off, dev, stream))
+        return rc;
+    if (Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, kWgDz>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    else if (Cin == 2) hipLaunchKernelGGL((conv_first_wgrad_kernel<2, kWgDz>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    else hipLaunchKernelGGL((conv_first_wgrad_kernel<3, kWgDz>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+    SEGK_LAUNCH_CHECK();
+    hipLaunchKernelGGL(conv_first_wgrad_reduce_kernel, dim3(64), dim3(kFirstThreads), 0, st, (const float*)workspace, grid, (int)Cin, 64, dw,
+                       (flags >> 1) & 1);
+    SEGK_LAUNCH_CHECK();
+    return SEGK_OK;
 }
 
 extern "C" int segk_conv_first_wgrad(const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const void* dy, int dy_dtype,

@@ -34,11 +34,15 @@ class conv_block_nested(SegkBlock):
         """Append the block to a segk tape.  x: Var / concat description; image: raw NCHW input of the first block;
         pool=True returns (output, maxpool2x2(output)), the pool fused into the last norm's passes."""
         zero = rt.training     # a bias in front of a batch-statistics norm has an identically zero gradient
-        if image is not None:
-            y = rt.conv_first(image, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
+        if image is not None and rt.can_fuse_first_norm(image, self.conv1.out_channels):
+            # convolution + norm + ReLU from the image, the convolution's output recomputed instead of stored
+            h = rt.conv_first_bn_relu(image, prefix + "conv1.weight", prefix + "conv1.bias", prefix + "bn1")
         else:
-            y = rt.conv(x, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
-        h = rt.bn_relu(y, prefix + "bn1", one_reader=True)
+            if image is not None:
+                y = rt.conv_first(image, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
+            else:
+                y = rt.conv(x, prefix + "conv1.weight", prefix + "conv1.bias", bias_grad_zero=zero, stats=True)
+            h = rt.bn_relu(y, prefix + "bn1", one_reader=True)
         y = rt.conv(h, prefix + "conv2.weight", prefix + "conv2.bias", bias_grad_zero=zero, stats=True)
         return rt.bn_relu(y, prefix + "bn2", out=out, pool=pool)
 

@@ -135,6 +135,10 @@ class _UNetVggBase(SegkNet):
                 v = pooled           # the max pool that opens this stage ran fused with the previous stage's last norm
             for j, _ in enumerate(stage_widths):
                 wn, bn_ = f"conv{k}.{idx}", f"conv{k}.{idx + 1}"
+                if k == 1 and j == 0 and v is None and rt.can_fuse_first_norm(x, stage_widths[0]):
+                    v = rt.conv_first_bn_relu(x, wn + ".weight", wn + ".bias", bn_)      # output of the convolution never stored
+                    idx += 3
+                    continue
                 if k == 1 and j == 0 and v is None:
                     y = rt.conv_first(x, wn + ".weight", wn + ".bias", bias_grad_zero=self.training, stats=True)
                 else:

@@ -36,6 +36,8 @@ _PROTOS = {
     "segk_conv_first_fwd": (I, [P, L, L, L, L, P, P, L, P, I, L, P, I, I, P]),
     "segk_conv_first_norm": (I, [I, P, L, L, L, L, P, P, L, P, P, P, P, P, L, P, L, P, I, P]),
     "segk_norm_bwd_sums_finalize": (I, [P, L, L, P, P, P, I, P, Z, I, P]),
+    "segk_conv_first_norm_bwd_workspace": (Z, [L, L, L]),
+    "segk_conv_first_norm_bwd": (I, [P, L, L, L, L, P, P, P, P, P, P, L, P, P, P, I, P, Z, I, P]),
     "segk_conv_first_wgrad_workspace": (Z, [L, L, L]),
     "segk_conv_first_wgrad": (I, [P, L, L, L, L, P, I, L, L, P, I, P, Z, I, P]),
     "segk_conv_krow": (I, [I]),

@@ -19,6 +19,7 @@ from .ops import Act
 
 
 _NO_FIRST_DIRECT = bool(os.environ.get("SEGK_NO_FIRST_DIRECT"))   # experiments: first convolution as a 1x1 convolution over a patch image
+_NO_FIRST_NORM_FUSE = bool(os.environ.get("SEGK_NO_FIRST_NORM_FUSE"))   # experiments: first convolution's output stored, BatchNorm as separate passes
 _NO_CONV_STATS = bool(os.environ.get("SEGK_NO_CONV_STATS"))   # experiments: separate statistics pass after every convolution
 # Weight gradients on a second stream: a convolution's weight and data gradients only share their input dy, so the two
 # kernels can run side by side and fill each other's tails and the under-occupied small layers (gradients are bitwise
@@ -297,6 +298,51 @@ class Runtime:
                 self._emit(bname, gb)
         self.record(bwd)
         return y
+
+    def can_fuse_first_norm(self, x, Cout):
+        """Whether conv_first_bn_relu serves this first layer: the bf16 path on an image of up to three channels, 64 output
+        channels, batch statistics (training mode)."""
+        return (self.training and Cout == 64 and ops.conv_first_direct_ok(x, Cout, self.dtype) and not _NO_FIRST_DIRECT
+                and not _NO_FIRST_NORM_FUSE)
+
+    def conv_first_bn_relu(self, x, wname, bname, prefix, eps=1e-5, momentum=0.1):
+        """Conv2d(Cin <= 3, 64, 3, padding=1) -> BatchNorm2d (batch statistics) -> ReLU on the fp32 NCHW image
+        (models/unetvgg.py:72 features[0..2]; models/unetplusplus.py:11-12 of conv0_0).  The convolution's 64-channel output is
+        never stored: statistics, the normalised output, the backward's two sums and the gradient that the weight gradient
+        reads are each computed from the image again (a few matrix steps per tile), which costs far less than moving a
+        64-channel tensor through HBM four more times."""
+        w = self.p[wname]
+        Cout = w.shape[0]
+        N, _, H, W = x.shape
+        bias = self._bias(bname)
+        gamma, beta = self.p[prefix + ".weight"].detach(), self.p[prefix + ".bias"].detach()
+        stats = torch.empty(2 * Cout, dtype=torch.float32, device=self.device)
+        part = ops.conv_first_norm(1, x, w, bias)
+        ops.norm_stats_from_partials(part, 1, N * H * W, eps, stats, self.b[prefix + ".running_mean"], self.b[prefix + ".running_var"], momentum)
+        self.counters.append(self.b[prefix + ".num_batches_tracked"])
+        a = Var(self.new(N, H, W, Cout))
+        ops.conv_first_norm(2, x, w, bias, stats=stats, gamma=gamma, beta=beta, out=a.act)
+
+        def bwd():
+            da = self.grad_of(a.act)
+            dg, db = self.alloc_grad(prefix + ".weight", gamma), self.alloc_grad(prefix + ".bias", beta)
+            gw = self.alloc_grad(wname, w)
+            # two passes over da: the norm's sums, then dL/dz formed inside the weight gradient's LDS stage
+            if gw.is_contiguous():
+                ops.conv_first_norm_bwd(x, w, bias, stats, gamma, beta, da, gw, dg, db)
+            else:
+                tmp = torch.empty_like(w, dtype=torch.float32)
+                ops.conv_first_norm_bwd(x, w, bias, stats, gamma, beta, da, tmp, dg, db)
+                gw.copy_(tmp)
+            self._emit(wname, gw)
+            if bname is not None:                 # the gradient reaching a bias in front of batch statistics sums to zero
+                gb = self.alloc_grad(bname, self.p[bname])
+                self._zero_grad(bname, gb)
+                self._emit(bname, gb)
+            self._emit(prefix + ".weight", dg)
+            self._emit(prefix + ".bias", db)
+        self.record(bwd)
+        return a
 
     def _bias(self, bname, cs=None):
         if bname is None:

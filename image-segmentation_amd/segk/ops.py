@@ -4,6 +4,8 @@ Activations are `Act` views: channels [c0, c0+C) of an NHWC buffer [N,H,W,ld].  
 straight into a channel slice of a wider buffer, which is how torch.cat of the reference
 (models/unetvgg.py:99-103) disappears.
 """
+import contextlib
+
 import torch
 
 from . import _lib
@@ -154,11 +156,27 @@ def conv_first_norm(mode, x, w, bias, stats=None, gamma=None, beta=None, red=Non
     if mode in (1, 3):
         part = torch.empty(query("segk_conv_first_stat_rows", N, H, W), 2, Cout, dtype=torch.float32, device=x.device)
     dev, st = _env(x)
-    with _Timed("conv_fwd", 2.0 * N * H * W * Cout * 32, "first layer"):
+    # only the pass that produces the layer's output counts as the convolution's forward in the roofline timer; the
+    # others stand where BatchNorm's streaming passes stood
+    with (_Timed("conv_fwd", 2.0 * N * H * W * Cout * 32, "first layer") if mode == 2 else contextlib.nullcontext()):
         call("segk_conv_first_norm", mode, x.data_ptr(), N, Cin, H, W, w.detach().contiguous().data_ptr(), _p(bias), Cout, _p(stats),
              _p(gamma), _p(beta), _p(red), g.ptr if g is not None else None, g.ld if g is not None else 0,
              out.ptr if out is not None else None, out.ld if out is not None else 0, _p(part), dev, st)
     return part
+
+
+def conv_first_norm_bwd(x, w, bias, stats, gamma, beta, g, dw, dgamma, dbeta):
+    """Backward of the fused first layer (conv_first_norm): weight gradient of the convolution and dgamma/dbeta of the norm
+    from g = gradient of relu(norm(conv(x))), in two passes over g that recompute the convolution."""
+    N, Cin, H, W = x.shape
+    assert g.C == 64 and g.dtype == torch.bfloat16 and tuple(dw.shape) == (64, Cin, 3, 3) and dw.is_contiguous()
+    x = x.contiguous().float()
+    dev, st = _env(x)
+    ws = workspace(query("segk_conv_first_norm_bwd_workspace", N, H, W), x.device)
+    with _Timed("conv_wgrad", 2.0 * N * H * W * 64 * 32):
+        call("segk_conv_first_norm_bwd", x.data_ptr(), N, Cin, H, W, w.detach().contiguous().data_ptr(), _p(bias), stats.data_ptr(),
+             _p(gamma), _p(beta), g.ptr, g.ld, dw.data_ptr(), _p(dgamma), _p(dbeta), 0, ws.data_ptr(), ws.numel(), dev, st)
+    return dw
 
 
 def norm_bwd_sums_finalize(partials, red, dgamma=None, dbeta=None, accumulate=False):

@@ -141,6 +141,18 @@ int segk_conv_first_norm(int mode, const float* x, int64_t N, int64_t Cin, int64
                          const float* red, const void* g, int64_t ldg, void* out, int64_t ld_out, float* partials, int dev,
                          void* stream);
 
+/* The whole backward of that fused first layer from g = dL/d relu(norm(z)) (bf16 NHWC, 64 channels): dw (fp32
+ * [64, Cin, 3, 3]), dgamma, dbeta (flags bit1: all three accumulated).  Two streaming passes over g, each recomputing z
+ * per tile: the first reduces the norm's two sums, the second turns g into dL/dz inside the LDS stage of the weight
+ * gradient -- neither z nor dL/dz is ever written to memory.  (The bias gradient of a convolution in front of batch
+ * statistics is identically zero.)  Deterministic: fixed-order reductions.
+ * replaces: the backward of features[0..2], models/unetvgg.py:72; of conv1/bn1 of conv0_0, models/unetplusplus.py:11-12. */
+size_t segk_conv_first_norm_bwd_workspace(int64_t N, int64_t H, int64_t W);
+int segk_conv_first_norm_bwd(const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const float* w, const float* bias,
+                             const float* stats, const float* gamma, const float* beta, const void* g, int64_t ldg, float* dw,
+                             float* dgamma, float* dbeta, int flags, void* workspace, size_t workspace_bytes, int dev,
+                             void* stream);
+
 /* Weight gradient of that first convolution, again straight from the image: dw (fp32, the module's [64, Cin, 3, 3]
  * layout) = sum over pixels of dy (bf16 NHWC, 64 channels) x the 3x3 neighbourhood of x; per-workgroup partial blocks
  * are added in fixed order (deterministic).  flags bit1: dw += result.

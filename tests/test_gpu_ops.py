@@ -178,6 +178,14 @@ def test_first_conv_with_norm_recomputed(cin):
     ops.conv_first_norm(4, xc, wc, bc, stats=stats, gamma=gc, beta=btc, red=red, g=ga, out=dz)
     assert rel_l2(from_act(dz), z.grad) < 1e-2, rel_l2(from_act(dz), z.grad)      # bf16 storage of dz: 4e-3
     report("stem_dz", from_act(dz), z.grad, rtol=2e-2, atol=2e-2 * float(z.grad.abs().max()))
+    # the whole backward in two passes over g, dL/dz kept inside the weight-gradient kernel's LDS stage
+    dw = torch.empty(C, cin, 3, 3, device="cuda")
+    dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.conv_first_norm_bwd(xc, wc, bc, stats, gc, btc, ga, dw, dg2, db2)
+    ref_dw = torch.nn.grad.conv2d_weight(x.double(), w.shape, z.grad, padding=1)
+    assert rel_l2(dg2.cpu(), gm.grad) < 2e-3 and rel_l2(db2.cpu(), bt.grad) < 2e-3, (rel_l2(dg2.cpu(), gm.grad), rel_l2(db2.cpu(), bt.grad))
+    assert rel_l2(dw.cpu(), ref_dw) < 1e-2, rel_l2(dw.cpu(), ref_dw)
+    report("stem_dw", dw.cpu(), ref_dw, rtol=2e-2, atol=2e-2 * float(ref_dw.abs().max()))
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
