@@ -80,6 +80,16 @@ def test_argument_validation_needs_no_gpu():
     # the forward convolution packs (pixel index << 3) into 32 bits: 2^28 pixels and more per launch are refused, not mis-addressed
     with pytest.raises(_lib.SegkError, match="2\\^28"):
         _lib.call("segk_conv_fwd", BF16, 9, 16, 64, 64, None, 0, 0, 1 << 12, 256, 256, 16, 64, None, 16, 64, None, 0, 0, None, 0, 0, None, 0, 0, None)
+    # the fused first layer (convolution output recomputed): modes 1..4, 64 output channels, statistics for modes 2-4
+    with pytest.raises(_lib.SegkError, match="mode"):
+        _lib.call("segk_conv_first_norm", 5, 16, 1, 3, 16, 16, 16, None, 64, None, None, None, None, None, 0, None, 0, 16, 0, None)
+    with pytest.raises(_lib.SegkError, match="statistics"):
+        _lib.call("segk_conv_first_norm", 2, 16, 1, 3, 16, 16, 16, None, 64, None, None, None, None, None, 0, 16, 64, None, 0, None)
+    with pytest.raises(_lib.SegkError, match="SEGK_EWORKSPACE"):
+        _lib.call("segk_conv_first_norm_bwd", 16, 1, 3, 16, 16, 16, None, 16, None, None, 16, 64, 16, None, None, 0, 16, 16, 0, None)
+    with pytest.raises(_lib.SegkError, match="pairs"):
+        _lib.call("segk_norm_bwd_sums_finalize", 16, 4, 64, 16, 16, None, 0, None, 0, 0, None)
+    assert _lib.query("segk_conv_first_norm_bwd_workspace", 32, 384, 384) > 512 * 64 * 32 * 4
     assert _lib.query("segk_norm_bwd_finish_workspace", 4096, 64) >= 2 * 64 * 4
     assert _lib.query("segk_conv_first_stat_rows", 32, 384, 384) > 0
 
