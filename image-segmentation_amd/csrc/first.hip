@@ -753,13 +753,20 @@ extern "C" int segk_conv_first_norm_bwd(const float* x, int64_t N, int64_t Cin, 
     a.red = red; a.inv_m = 1.f / (float)(N * H * W);
     const int grid = first_wgrad_grid(a.ntiles);
     hipStream_t st = (hipStream_t)stream;
-    if (Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
-    else if (Cin == 2) hipLaunchKernelGGL((conv_first_wgrad_kernel<2, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
-    else hipLaunchKernelGGL((conv_first_wgrad_kernel<3, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
-    SEGK_LAUNCH_CHECK();
-    if (int rc = segk_norm_bwd_sums_finalize(a.part, (int64_t)grid * 4, 64, red, dgamma, dbeta, flags & 2, (char*)workspace + fin_off,
-                                             need - fin_off, dev, stream))
-        return rc;
+    // flags bit2: the norm's half only (first pass + reduction: dgamma, dbeta, the two sums left in the workspace);
+    // flags bit3: the convolution's half only (second pass, from the sums a bit2 call left in the same workspace)
+    const bool norm_half = !(flags & 8), conv_half = !(flags & 4);
+    SEGK_REQUIRE(norm_half || conv_half, SEGK_EINVAL, "conv_first_norm_bwd: flags bit2 and bit3 exclude each other");
+    if (norm_half) {
+        if (Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+        else if (Cin == 2) hipLaunchKernelGGL((conv_first_wgrad_kernel<2, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+        else hipLaunchKernelGGL((conv_first_wgrad_kernel<3, kWgSums>), dim3(grid), dim3(kFirstThreads), 0, st, a);
+        SEGK_LAUNCH_CHECK();
+        if (int rc = segk_norm_bwd_sums_finalize(a.part, (int64_t)grid * 4, 64, red, dgamma, dbeta, flags & 2, (char*)workspace + fin_off,
+                                                 need - fin_off, dev, stream))
+            return rc;
+    }
+    if (!conv_half) return SEGK_OK;
     if (Cin == 1) hipLaunchKernelGGL((conv_first_wgrad_kernel<1, kWgDz>), dim3(grid), dim3(kFirstThreads), 0, st, a);
     else if (Cin == 2) hipLaunchKernelGGL((conv_first_wgrad_kernel<2, kWgDz>), dim3(grid), dim3(kFirstThreads), 0, st, a);
     else hipLaunchKernelGGL((conv_first_wgrad_kernel<3, kWgDz>), dim3(grid), dim3(kFirstThreads), 0, st, a);

@@ -145,7 +145,9 @@ int segk_conv_first_norm(int mode, const float* x, int64_t N, int64_t Cin, int64
  * [64, Cin, 3, 3]), dgamma, dbeta (flags bit1: all three accumulated).  Two streaming passes over g, each recomputing z
  * per tile: the first reduces the norm's two sums, the second turns g into dL/dz inside the LDS stage of the weight
  * gradient -- neither z nor dL/dz is ever written to memory.  (The bias gradient of a convolution in front of batch
- * statistics is identically zero.)  Deterministic: fixed-order reductions.
+ * statistics is identically zero.)  Deterministic: fixed-order reductions.  flags bit2: the norm's half only (first pass:
+ * dgamma, dbeta, the sums kept in the workspace); bit3: the convolution's half only (second pass: dw, from the sums a
+ * bit2 call left in the same workspace) -- for callers that time or schedule the two halves separately.
  * replaces: the backward of features[0..2], models/unetvgg.py:72; of conv1/bn1 of conv0_0, models/unetplusplus.py:11-12. */
 size_t segk_conv_first_norm_bwd_workspace(int64_t N, int64_t H, int64_t W);
 int segk_conv_first_norm_bwd(const float* x, int64_t N, int64_t Cin, int64_t H, int64_t W, const float* w, const float* bias,

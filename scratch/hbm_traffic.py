@@ -4,6 +4,7 @@ Both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 b
 import collections
 import csv
 import json
+import re
 import sys
 
 
@@ -23,7 +24,9 @@ for name in sorted(fetch, key=lambda k: -sum(fetch[k]) * 2 - sum(write.get(k, []
     rd, wr = 2 * sum(fetch[name]), sum(write.get(name, []))
     n = len(fetch[name])
     total += rd + wr
-    if any(k in name for k in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_wgrad_reduce_kernel", "conv_first_")):   # what bench.py times as convolution
+    # what bench.py times as convolution; the statistics-only and sums passes of the fused first layer stand in for BatchNorm passes
+    norm_pass = re.search(r"conv_first_fwd_kernel<\d+, \d+, 1>|conv_first_wgrad_kernel<\d+, 1>", name) is not None
+    if any(k in name for k in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_wgrad_reduce_kernel", "conv_first_")) and not norm_pass:
         conv += rd + wr
     kernels[name] = {"launches_per_step": round(n / steps, 2), "hbm_read_bytes_per_launch": int(rd / n),
                      "hbm_write_bytes_per_launch": int(wr / n)}
