@@ -140,7 +140,7 @@ def test_first_conv_with_norm_recomputed(cin):
     recomputed from the image in every pass instead of stored (segk_conv_first_norm modes 1-4)."""
     from segk import ops
     from util import rel_l2
-    N, H, W, C = 2, 24, 80, 64                      # W: one full 64-column tile and a partial one
+    N, H, W, C = 2, 20, 80, 64                      # partial tiles in both directions (tiles are 8 x 64 and 8 x 32 pixels)
     bf = torch.bfloat16
     x = rnd((N, cin, H, W), bf, 21)
     w = rnd((C, cin, 3, 3), bf, 22, scale=0.4)
