@@ -186,6 +186,15 @@ def test_first_conv_with_norm_recomputed(cin):
     assert rel_l2(dg2.cpu(), gm.grad) < 2e-3 and rel_l2(db2.cpu(), bt.grad) < 2e-3, (rel_l2(dg2.cpu(), gm.grad), rel_l2(db2.cpu(), bt.grad))
     assert rel_l2(dw.cpu(), ref_dw) < 1e-2, rel_l2(dw.cpu(), ref_dw)
     report("stem_dw", dw.cpu(), ref_dw, rtol=2e-2, atol=2e-2 * float(ref_dw.abs().max()))
+    # ops.conv_first_norm_bwd issues the two halves as two calls (flags 4, then 8); one call with flags 0 gives the same bits
+    from segk import _lib
+    dw1 = torch.empty_like(dw)
+    dg3, db3 = torch.empty_like(dg2), torch.empty_like(db2)
+    ws = ops.workspace(_lib.query("segk_conv_first_norm_bwd_workspace", N, H, W), xc.device)
+    _lib.call("segk_conv_first_norm_bwd", xc.data_ptr(), N, cin, H, W, wc.data_ptr(), bc.data_ptr(), stats.data_ptr(), gc.data_ptr(),
+              btc.data_ptr(), ga.ptr, ga.ld, dw1.data_ptr(), dg3.data_ptr(), db3.data_ptr(), 0, ws.data_ptr(), ws.numel(), 0,
+              torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(dw1, dw) and torch.equal(dg3, dg2) and torch.equal(db3, db2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
