@@ -187,6 +187,9 @@ def main():
     ap.add_argument("--no-wgrad-stream", action="store_true",
                     help="keep the weight gradients on the main stream (default: on a second HIP stream next to the data gradients, "
                          "except on the steps whose launches are event-timed and with more than one rank)")
+    ap.add_argument("--launch-table", default=None,
+                    help="also write the event-timed duration of every convolution launch of a step (mean over the event-timed steps, "
+                         "in launch order, with its shape) to this JSON file")
     args = ap.parse_args()
     if os.environ.get("SEGK_BENCH_TRACE_AFTER"):      # debugging aid: dump every thread's Python stack and exit if still running after N seconds
         import faulthandler
@@ -375,18 +378,28 @@ def main():
                        "value_if_h2d_not_overlapped": round(world * args.batch * args.steps / (elapsed + args.steps * h2d_ms / 1e3), 2)},
         }
         if timer:
-            fwd = sum(a.elapsed_time(b) for k, a, b, _, _ in timer if k == "conv_fwd")
-            wg = sum(a.elapsed_time(b) for k, a, b, _, _ in timer if k == "conv_wgrad")
+            fwd = sum(a.elapsed_time(b) for k, a, b, *_ in timer if k == "conv_fwd")
+            wg = sum(a.elapsed_time(b) for k, a, b, *_ in timer if k == "conv_wgrad")
             # the same events per kernel family, with the FLOP each launch actually multiplied (the 27-value patch row of the
             # first convolution counts as its 32 stored channels, so the sum is 0.1 % above the algorithmic figure)
             fam = {}
-            for k, a, b, fl, variant in timer:
+            for k, a, b, fl, variant, _ in timer:
                 name = "conv_wgrad_kernel" if k == "conv_wgrad" else f"conv_fwd_kernel[{variant}]"
                 ms_, fl_, n_ = fam.get(name, (0.0, 0.0, 0))
                 fam[name] = (ms_ + a.elapsed_time(b), fl_ + fl, n_ + 1)
             conv_ms = (fwd + wg) / timed_steps
+            if args.launch_table:
+                per = len(timer) // timed_steps
+                rows = []
+                for i in range(per):
+                    k, _, _, fl, variant, desc = timer[i]
+                    us = [1e3 * timer[s_ * per + i][1].elapsed_time(timer[s_ * per + i][2]) for s_ in range(timed_steps)]
+                    rows.append({"i": i, "kind": k, "variant": variant, "shape": desc, "gflop": round(fl / 1e9, 2),
+                                 "us_mean": round(sum(us) / len(us), 1), "us_min": round(min(us), 1), "us_max": round(max(us), 1)})
+                with open(args.launch_table, "w") as f:
+                    json.dump(rows, f, indent=0)
             if gflop is None:      # FLOP as launched (channel padding included), per slice
-                gflop = sum(fl for _, _, _, fl, _ in timer) / timed_steps / args.batch / 1e9
+                gflop = sum(fl for _, _, _, fl, _, _ in timer) / timed_steps / args.batch / 1e9
             achieved = gflop * args.batch / conv_ms        # GFLOP / ms = TFLOP/s
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             # HBM bytes of the same launches (one step) from the committed PMC passes of this workload; null for other workloads

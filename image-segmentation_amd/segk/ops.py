@@ -74,14 +74,14 @@ def _env(t):
 _workspaces = {}
 
 # Optional per-launch timing of the MFMA convolutions (bench.py's roofline leg): a list that receives
-# (kind, start_event, end_event, algorithmic FLOP, kernel variant) for every conv launch, recorded on the stream the
-# kernel runs on.
+# (kind, start_event, end_event, algorithmic FLOP, kernel variant, shape text) for every conv launch, recorded on the
+# stream the kernel runs on.
 CONV_TIMER = None
 
 
 class _Timed:
-    def __init__(self, kind, flops=0.0, variant=""):
-        self.kind, self.flops, self.variant = kind, flops, variant
+    def __init__(self, kind, flops=0.0, variant="", desc=""):
+        self.kind, self.flops, self.variant, self.desc = kind, flops, variant, desc
 
     def __enter__(self):
         if CONV_TIMER is not None:
@@ -92,7 +92,7 @@ class _Timed:
         if CONV_TIMER is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            CONV_TIMER.append((self.kind, self.e0, e1, self.flops, self.variant))
+            CONV_TIMER.append((self.kind, self.e0, e1, self.flops, self.variant, self.desc))
 
 
 def workspace(nbytes, device):
@@ -263,7 +263,8 @@ def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, a
     dev, st = _env(a.buf)
     flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (4 if accumulate1 else 0)
     cin = a.C + (b.C if b else 0)
-    with _Timed("conv_fwd", 2.0 * a.P * Cout * cin * taps, "128-wide" if (Cout + 31) // 32 * 32 % 128 == 0 else "narrow"):
+    with _Timed("conv_fwd", 2.0 * a.P * Cout * cin * taps, "128-wide" if (Cout + 31) // 32 * 32 % 128 == 0 else "narrow",
+                f"{a.H}^2 {cin}->{Cout} k{taps}"):
         call("segk_conv_fwd", dt(a.dtype), taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0,
              a.N, a.H, a.W, w_packed.data_ptr(), Cout, _p(bias), o0.ptr, o0.ld, o1.ptr if o1 else None, o1.ld if o1 else 0,
              o0.C if o1 else 0, mask.ptr if mask else None, mask.ld if mask else 0, mask.C if mask else 0, _p(stat_partials), flags,
@@ -305,7 +306,7 @@ def conv_wgrad(x, dy, dw, taps=9, cin_real=None, accumulate=False):
     d = dt(a.dtype)
     nbytes = query("segk_conv_wgrad_workspace", d, taps, a.C, b.C if b else 0, a.N, a.H, a.W, Cout)
     ws = workspace(nbytes, a.device)
-    with _Timed("conv_wgrad", 2.0 * a.P * Cout * cin * taps):
+    with _Timed("conv_wgrad", 2.0 * a.P * Cout * cin * taps, "", f"{a.H}^2 {cin}->{Cout} k{taps}"):
         call("segk_conv_wgrad", d, taps, a.ptr, a.ld, a.C, b.ptr if b else None, b.ld if b else 0, b.C if b else 0, a.N, a.H,
              a.W, dy.ptr, dy.ld, Cout, cin_real, dw.data_ptr(), ACCUM if accumulate else 0, ws.data_ptr(), ws.numel(), dev, st)
     return dw
