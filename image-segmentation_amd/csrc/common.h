@@ -78,6 +78,16 @@ template <> struct Elem<float> {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
+    // streaming variants: non-temporal accesses for tensors that are swept once per kernel
+    static __device__ __forceinline__ void load8s(const float* p, float (&v)[8]) {
+        const f32x4 a = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        const f32x4 b = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p + 4));
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    }
+    static __device__ __forceinline__ void store8s(float* p, const float (&v)[8]) {
+        __builtin_nontemporal_store(f32x4{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(p));
+        __builtin_nontemporal_store(f32x4{v[4], v[5], v[6], v[7]}, reinterpret_cast<f32x4*>(p + 4));
+    }
     static __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
         const float4 a = *reinterpret_cast<const float4*>(p);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -100,6 +110,17 @@ template <> struct Elem<bf16> {
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
         *reinterpret_cast<bf16x8*>(p) = a;
+    }
+    static __device__ __forceinline__ void load8s(const bf16* p, float (&v)[8]) {
+        const bf16x8 a = __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+    static __device__ __forceinline__ void store8s(bf16* p, const float (&v)[8]) {
+        bf16x8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (bf16)v[i];
+        __builtin_nontemporal_store(a, reinterpret_cast<bf16x8*>(p));
     }
     static __device__ __forceinline__ void load4(const bf16* p, float (&v)[4]) {
         const bf16x4 a = *reinterpret_cast<const bf16x4*>(p);

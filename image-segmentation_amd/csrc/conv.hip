@@ -1296,12 +1296,15 @@ static void launch_wgrad_t(int dtype, const WgradArgs& a, unsigned grid, hipStre
     // tiling variant: skip the zero half of a 64-channel bf16 K-row when dy (or a single-K-row input) has <= 32 channels
     const bool thin_co = dtype == SEGK_BF16 && Cout <= 32;
     const bool thin_ci = dtype == SEGK_BF16 && !thin_co && a.nch == 1 && C0 <= 32;
+    static const int wave_layout = getenv("SEGK_WGRAD_LAYOUT") ? atoi(getenv("SEGK_WGRAD_LAYOUT")) : 22;   // experiment switch
     if (dtype == SEGK_F32)
         hipLaunchKernelGGL((conv_wgrad_kernel<float, TAPS, 2, 2, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else if (thin_co)
         hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS, 2, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else if (thin_ci)
         hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS, 4, 2, 4, 1>), dim3(grid), dim3(kConvThreads), 0, st, a);
+    else if (wave_layout == 14)
+        hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS, 4, 4, 1, 4>), dim3(grid), dim3(kConvThreads), 0, st, a);
     else
         hipLaunchKernelGGL((conv_wgrad_kernel<bf16, TAPS, 4, 4, 2, 2>), dim3(grid), dim3(kConvThreads), 0, st, a);
 }

@@ -647,6 +647,8 @@ extern "C" int segk_conv_first_fwd(const float* x, int64_t N, int64_t Cin, int64
     SEGK_REQUIRE(Cout == 32 || Cout == 64, SEGK_ESHAPE, "conv_first_fwd: %lld output channels (32 or 64)", (long long)Cout);
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_first_fwd: bad N/H/W");
     SEGK_REQUIRE(ldy >= Cout && aligned16(y) && (ldy * 2) % 16 == 0, SEGK_EALIGN, "conv_first_fwd: output pointer/ld misaligned or ld < Cout");
+    SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "conv_first_fwd: bias must be 16-byte aligned");
+    SEGK_REQUIRE(!stat_partials || aligned16(stat_partials), SEGK_EALIGN, "conv_first_fwd: statistics partials must be 16-byte aligned");
     SEGK_USE_DEVICE(dev);
     FirstArgs a;
     a.x = x; a.w = w; a.bias = bias; a.y = (bf16*)y; a.ldy = ldy; a.stat_part = stat_partials;
@@ -682,6 +684,7 @@ extern "C" int segk_conv_first_norm(int mode, const float* x, int64_t N, int64_t
     SEGK_REQUIRE(mode < kBwdSums || (g && ldg >= Cout && aligned16(g) && (ldg * 2) % 16 == 0), SEGK_EALIGN,
                  "conv_first_norm: modes 3 and 4 need an aligned bf16 gradient with ld >= Cout");
     SEGK_REQUIRE(mode != kBwdDz || red, SEGK_EINVAL, "conv_first_norm: mode 4 needs the reduced sums");
+    SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "conv_first_norm: bias must be 16-byte aligned");
     SEGK_USE_DEVICE(dev);
     FirstArgs a;
     a.x = x; a.w = w; a.bias = bias; a.y = (bf16*)out; a.ldy = ld_out; a.stat_part = sums ? partials : nullptr;
@@ -738,6 +741,7 @@ extern "C" int segk_conv_first_norm_bwd(const float* x, int64_t N, int64_t Cin, 
     SEGK_REQUIRE(N > 0 && H > 0 && W > 0 && N * H * W < (1ll << 31), SEGK_ESHAPE, "conv_first_norm_bwd: bad N/H/W");
     SEGK_REQUIRE(ldg >= 64 && aligned16(g) && (ldg * 2) % 16 == 0, SEGK_EALIGN, "conv_first_norm_bwd: gradient pointer/ld misaligned or ld < 64");
     SEGK_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), SEGK_EINVAL, "conv_first_norm_bwd: dgamma/dbeta come in pairs");
+    SEGK_REQUIRE(!bias || aligned16(bias), SEGK_EALIGN, "conv_first_norm_bwd: bias must be 16-byte aligned");
     size_t part_off, red_off, fin_off;
     const size_t need = first_norm_bwd_sections(N, H, W, &part_off, &red_off, &fin_off);
     SEGK_REQUIRE(workspace_bytes >= need, SEGK_EWORKSPACE, "conv_first_norm_bwd: workspace too small");

@@ -443,10 +443,11 @@ extern "C" int segk_dice_focal_fwd(const void* logits, int logits_dtype, const i
 // The same forward for callers that cannot allocate (HIP graph capture, tight serving loops): the block partials go to
 // a fixed device array of this code object instead of a caller-provided workspace.  `scratch` is only a host-side
 // stand-in for the symbol; the device address is looked up once per device with hipGetSymbolAddress and that pointer
-// is what the kernels receive.  Every GPU holds its own copy of the array until the process ends.
+// is what the kernels receive.  Every GPU holds its own copy of the array until the process ends.  That look-up (the
+// first call on a device) is not a capturable operation: callers warm the entry point up once per device before capturing.
 // ----------------------------------------------------------------------------------------------
 namespace segk {
-constexpr size_t kStaticScratchBytes = 1u << 20;     // 1 MiB: e.g. 2978 images x 4 classes at 384 x 384
+constexpr size_t kStaticScratchBytes = 1u << 20;     // 1 MiB; what a shape needs: segk_dice_focal_workspace(N, C, HW)
 constexpr int kMaxDevices = 64;
 static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 static void* g_scratch_ptr[kMaxDevices] = {};

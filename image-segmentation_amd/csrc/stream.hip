@@ -9,6 +9,15 @@ namespace segk {
 
 constexpr int kThreads = 256;
 
+// experiment switch: non-temporal accesses in the normalisation passes
+#ifdef SEGK_STREAM_NT
+#define LD8S load8s
+#define ST8S store8s
+#else
+#define LD8S load8
+#define ST8S store8
+#endif
+
 static inline int grid_for(int64_t items, int cap = 8192) {
     int64_t g = (items + kThreads - 1) / kThreads;
     if (g > cap) g = cap;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restric
     for (; p + 3 * step < M; p += 4 * step) {
         float a[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Elem<T>::load8(xb + (p + u * step) * ldx, a[u]);
+        for (int u = 0; u < 4; ++u) Elem<T>::LD8S(xb + (p + u * step) * ldx, a[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -233,18 +242,18 @@ __global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restric
                 a[u][j] = a[u][j] * sc[j] + sh[j];
                 if (relu) a[u][j] = fmaxf(a[u][j], 0.f);
             }
-            Elem<T>::store8(yb + (p + u * step) * ldy, a[u]);
+            Elem<T>::ST8S(yb + (p + u * step) * ldy, a[u]);
         }
     }
     for (; p < M; p += step) {
         float a[8];
-        Elem<T>::load8(xb + p * ldx, a);
+        Elem<T>::LD8S(xb + p * ldx, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             a[j] = a[j] * sc[j] + sh[j];
             if (relu) a[j] = fmaxf(a[j], 0.f);
         }
-        Elem<T>::store8(yb + p * ldy, a);
+        Elem<T>::ST8S(yb + p * ldy, a);
     }
 }
 
@@ -278,8 +287,8 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __r
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
     for (int64_t p = lo + r; p < hi && r < rows; p += rows) {   // r >= rows: spare threads when C/8 does not divide the block
         float a[8], d[8];
-        Elem<T>::load8(xb + p * ldx, a);
-        Elem<T>::load8(db + p * ld_dy, d);
+        Elem<T>::LD8S(xb + p * ldx, a);
+        Elem<T>::LD8S(db + p * ld_dy, d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sc = rstd[j] * ga[j];
@@ -348,8 +357,8 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
     T* ob = dx + (int64_t)g * M * ld_dx + v * 8;
     for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M && r < rows; p += (int64_t)gridDim.x * rows) {
         float a[8], d[8];
-        Elem<T>::load8(xb + p * ldx, a);
-        Elem<T>::load8(db + p * ld_dy, d);
+        Elem<T>::LD8S(xb + p * ldx, a);
+        Elem<T>::LD8S(db + p * ld_dy, d);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sc = rstd[j] * ga[j];
@@ -360,11 +369,11 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
         }
         if (add_dx) {
             float o[8];
-            Elem<T>::load8(ob + p * ld_dx, o);
+            Elem<T>::LD8S(ob + p * ld_dx, o);
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] += o[j];
         }
-        Elem<T>::store8(ob + p * ld_dx, d);
+        Elem<T>::ST8S(ob + p * ld_dx, d);
     }
 }
 
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(kThreads) void norm_pool_apply_kernel(const T* __re
         const int64_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
         float a[4][8], m[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Elem<T>::load8(x + off[k] * ldx + v * 8, a[k]);
+        for (int k = 0; k < 4; ++k) Elem<T>::LD8S(x + off[k] * ldx + v * 8, a[k]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -413,9 +422,9 @@ __global__ __launch_bounds__(kThreads) void norm_pool_apply_kernel(const T* __re
                 a[k][j] = fmaxf(a[k][j] * sc[j] + sh[j], 0.f);
                 m[j] = k == 0 ? a[k][j] : fmaxf(m[j], a[k][j]);
             }
-            Elem<T>::store8(y + off[k] * ldy + v * 8, a[k]);
+            Elem<T>::ST8S(y + off[k] * ldy + v * 8, a[k]);
         }
-        Elem<T>::store8(pool + q * ldp + v * 8, m);
+        Elem<T>::ST8S(pool + q * ldp + v * 8, m);
     }
 }
 
@@ -427,11 +436,11 @@ __device__ __forceinline__ void window_grad(const T* __restrict__ da, int64_t ld
                                             const float (&be)[8], float (&g)[4][8], float (&xh)[4][8]) {
     float pre[4][8], gp[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Elem<T>::load8(x + off[k] * ldx + v * 8, pre[k]);
-    Elem<T>::load8(dp + q * ld_dp + v * 8, gp);
+    for (int k = 0; k < 4; ++k) Elem<T>::LD8S(x + off[k] * ldx + v * 8, pre[k]);
+    Elem<T>::LD8S(dp + q * ld_dp + v * 8, gp);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (da) Elem<T>::load8(da + off[k] * ld_da + v * 8, g[k]);
+        if (da) Elem<T>::LD8S(da + off[k] * ld_da + v * 8, g[k]);
         else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[k][j] = 0.f;
@@ -536,7 +545,7 @@ __global__ __launch_bounds__(kThreads) void norm_pool_bwd_dx_kernel(const T* __r
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[k][j] = rstd[j] * ga[j] * (g[k][j] - m1[j] - xh[k][j] * m2[j]);
-            Elem<T>::store8(dx + off[k] * ld_dx + v * 8, g[k]);
+            Elem<T>::ST8S(dx + off[k] * ld_dx + v * 8, g[k]);
         }
     }
 }

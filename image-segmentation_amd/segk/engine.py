@@ -167,7 +167,7 @@ class Runtime:
             return
         s = side_stream(self.device)
         ev = torch.cuda.Event()
-        ev.record()
+        ev.record(torch.cuda.current_stream(self.device))     # the tape's device, which need not be the thread's current one
         s.wait_event(ev)
         with torch.cuda.stream(s):
             yield
@@ -178,7 +178,7 @@ class Runtime:
         if getattr(self, "_side_used", False):
             ev = torch.cuda.Event()
             ev.record(side_stream(self.device))
-            torch.cuda.current_stream().wait_event(ev)
+            torch.cuda.current_stream(self.device).wait_event(ev)
             self._side_used = False
 
     def release(self):

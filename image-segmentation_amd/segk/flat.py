@@ -45,19 +45,32 @@ class GradBuckets:
         # branch -- event, communication stream, all-reduce, scaling -- end to end; the result is the identity)
         self.active = self.world > 1 or (initialised and os.environ.get("SEGK_FORCE_COLLECTIVES") == "1")
         self.comm_stream = torch.cuda.Stream(device) if (device is not None and device.type == "cuda" and self.active) else None
+        self.exposed = None      # set to a list to collect (start, end) events around the compute stream's wait for the collectives
         self.reset()
 
     def reset(self):
         self.pending = list(self.expected)
         self.works, self.events = [], []
         self.launched = []
+        self.marked = set()
 
     def mark(self, name, flat_grad):
         b = self.bucket_of[name]
         self.pending[b] -= 1
-        assert self.pending[b] >= 0, f"gradient of {name} produced twice in one backward"
+        assert self.pending[b] >= 0 and name not in self.marked, f"gradient of {name} produced twice in one backward"
+        self.marked.add(name)
         if self.pending[b] == 0:
             self._launch(b, flat_grad)
+
+    def complete_missing(self, flat_grad):
+        """Parameters whose gradient no tape produced in this backward (a network whose output did not reach the loss):
+        their gradient is zero.  Write it and mark them, so that every bucket is reduced on every rank.  -> their names."""
+        missing = [n for n in self.offsets if n not in self.marked]
+        for n in missing:
+            off, cnt = self.offsets[n]
+            flat_grad[off:off + cnt].zero_()
+            self.mark(n, flat_grad)
+        return missing
 
     def _launch(self, b, flat_grad):
         self.launched.append(b)
@@ -87,8 +100,7 @@ class GradBuckets:
             with torch.cuda.stream(self.comm_stream):
                 for ev in pending:
                     self.comm_stream.wait_event(ev)
-                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group)
-                view.mul_(1.0 / self.world)
+                dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the collective: no scaling launch
                 done = torch.cuda.Event()
                 done.record()
             self.events.append(done)
@@ -98,6 +110,15 @@ class GradBuckets:
     def finish(self):
         """Make the reduced gradients visible to whatever runs next on the current stream."""
         assert all(p == 0 for p in self.pending), f"backward left buckets incomplete: {self.pending}"
+        if self.events and self.exposed is not None:
+            # how long the compute stream stands still for the collectives: events around the waits, read by the caller later
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for ev in self.events:
+                torch.cuda.current_stream().wait_event(ev)
+            e1.record()
+            self.exposed.append((e0, e1))
+            self.events = []
         for ev in self.events:
             torch.cuda.current_stream().wait_event(ev)
         for work, view in self.works:
@@ -161,17 +182,43 @@ class FlatModel:
                 for b in bufs:
                     b.data.copy_(flat[off:off + b.numel()].view_as(b))
                     off += b.numel()
-        # several tape networks under one wrapper (each run once per step) do their backward passes one after the other
-        # within ONE autograd backward: the bucket state is reset when the first starts and checked when the last is done
+        # Several tape networks under one wrapper do their backward passes one after the other within ONE autograd backward.
+        # The bucket state is reset when the first of them starts.  It is closed (gradients nobody produced zeroed, every
+        # bucket reduced, the compute stream made to wait for the collectives) by a callback queued on the autograd engine,
+        # which runs when that backward pass is over -- however many of the networks took part in it: one whose parameters are
+        # all frozen records no backward, and one whose output did not reach the loss is never called.  Hooks driven by hand
+        # outside a backward pass (tests) cannot queue a callback; then the pass closes when every network that has a
+        # trainable parameter has finished.
         self._done = 0
-        self._ntargets = len(targets)
+        self._open = False
+        self._queued = False
+        self._ntargets = sum(1 for prefix, m in targets if any(p.requires_grad for p in m.parameters()))
         for prefix, m in targets:
-            m._segk_grad_hooks = (self._make_sink(prefix), self._make_alloc(prefix), self._begin, self._finish)
+            m._segk_grad_hooks = (self._make_sink(prefix), self._make_alloc(prefix), self._begin, self._finish, self._on_forward)
 
     # hooks called by the tape
+    def _on_forward(self):
+        """A forward pass starts a new step: a backward pass that was cut short by an exception must not leave the state open."""
+        self._open = False
+
     def _begin(self):
-        if self._done == 0:
-            self.buckets.reset()
+        if self._open:
+            return
+        self._open = True
+        self._done = 0
+        self.buckets.reset()
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(self._close)
+            self._queued = True
+        except RuntimeError:                 # not inside a backward pass
+            self._queued = False
+
+    def _close(self):
+        if not self._open:
+            return
+        self._open = False
+        self.buckets.complete_missing(self.flat_grad)
+        self.buckets.finish()
 
     def _make_alloc(self, prefix):
         def alloc(name, like):
@@ -196,6 +243,5 @@ class FlatModel:
 
     def _finish(self):
         self._done += 1
-        if self._done >= self._ntargets:
-            self._done = 0
-            self.buckets.finish()
+        if not self._queued and self._done >= self._ntargets:
+            self._close()

@@ -1,5 +1,6 @@
 """Fused softmax + squared-Dice + focal loss on the GPU (autograd.Function over the C ABI) and the
 arg-max Dice metric.  CPU tensors are served by the same formulas in torch ops (`_host_*`)."""
+import threading
 import weakref
 
 import torch
@@ -47,7 +48,7 @@ class _DiceFocalFn(torch.autograd.Function):
         call("segk_dice_focal_finalize", sums.data_ptr(), iflags.data_ptr(), N, C, HW, flags, scalars.data_ptr(), dev, st)
         ctx.save_for_backward(z, labels if labels is not None else hot, sums, iflags, scalars)
         ctx.meta = (N, C, HW, float(gamma), al, flags, labels is not None, logits.dtype)
-        ctx.token = _SHARED.get("pending")      # set by dice_focal(): marks the shared node as spent once it has run backward
+        ctx.token = _store().get("pending")      # set by dice_focal(): marks the shared node as spent once it has run backward
         ctx.set_materialize_grads(False)
         outs = (scalars[0], scalars[1])
         if want_map:
@@ -84,8 +85,11 @@ def _as_square_labels(act):
 # (perlosstrain/naive_train.py:421-423, pl_utils/pl_mod.py:64-67).  The fused kernels compute both, so the second call
 # re-uses the autograd node of the first: one forward launch, and one backward launch that receives both upstream
 # gradients and writes dlogits once.  The entry is valid while both tensors are alive and unmodified, the focal
-# parameters agree, and the node has not run its backward yet.
-_SHARED = {}
+# parameters agree, and the node has not run its backward yet.  It is kept per host thread (two training loops in one
+# process do not see each other's entry), holds the logits weakly and is dropped as soon as the logits tensor dies, the
+# second loss has been served, or the node has run its backward; until then it keeps the target alive (so that its address
+# cannot be handed to another tensor and matched by mistake) together with the two 0-dim results.
+_SHARED = threading.local()
 
 
 def _same_data(a, b):
@@ -94,14 +98,33 @@ def _same_data(a, b):
                         and a._version == b._version)
 
 
+def _alpha_key(alpha):
+    """The class weights by value: a list object's id can be re-used by another list, and a tensor edited in place keeps its id."""
+    if alpha is None:
+        return None
+    if isinstance(alpha, torch.Tensor):
+        return ("tensor", alpha.data_ptr(), alpha._version, tuple(alpha.shape), alpha.dtype)
+    return tuple(float(a) for a in alpha)
+
+
+def _store():
+    """This host thread's slot dictionary (captured by the weak-reference callback, which may run on another thread)."""
+    return _SHARED.__dict__
+
+
 def _shared_lookup(pred, target, gamma, alpha, flags, grad):
-    e = _SHARED.get("entry")
-    if e is None or e["token"]["spent"]:
+    store = _store()
+    e = store.get("entry")
+    if e is None:
+        return None
+    if e["token"]["spent"]:
+        store["entry"] = None
         return None
     if e["pred"]() is not pred or e["versions"] != (pred._version, target._version) or not _same_data(e["target"], target):
         return None
-    if e["key"] != (float(gamma), None if alpha is None else id(alpha), flags, grad):
+    if e["key"] != (float(gamma), _alpha_key(alpha), flags, grad):
         return None
+    store["entry"] = None                     # the second loss of the pair has been served
     return e["outs"]
 
 
@@ -116,15 +139,19 @@ def dice_focal(pred, target, gamma=2.0, alpha=None, no_sft=False, is_all_chann=F
     if outs is not None:
         return outs
     token = {"spent": False}
-    _SHARED["pending"] = token
+    store = _store()
+    store["pending"] = token
     try:
         outs = _DiceFocalFn.apply(pred, target, gamma, alpha, flags, False)
     finally:
-        _SHARED["pending"] = None
-    # the logits are held weakly (large, and only the caller's own tensor can match again); the target strongly: the entry
-    # points pass views of it, and it is small
-    _SHARED["entry"] = {"pred": weakref.ref(pred), "target": target, "versions": (pred._version, target._version),
-                        "key": (float(gamma), None if alpha is None else id(alpha), flags, grad), "token": token, "outs": outs}
+        store["pending"] = None
+
+    def gone(_ref, token=token, store=store):        # the logits tensor died: nothing can match this entry any more
+        e = store.get("entry")
+        if e is not None and e["token"] is token:
+            store["entry"] = None
+    store["entry"] = {"pred": weakref.ref(pred, gone), "target": target, "versions": (pred._version, target._version),
+                     "key": (float(gamma), _alpha_key(alpha), flags, grad), "token": token, "outs": outs}
     return outs
 
 

@@ -31,7 +31,9 @@ class _TapeFn(torch.autograd.Function):
     def forward(ctx, net, x, need_grad, *params):
         names = net._segk_param_names
         dtype = net.compute_dtype()
-        hooks = getattr(net, "_segk_grad_hooks", None) or (None, None, None, None)
+        hooks = getattr(net, "_segk_grad_hooks", None) or (None, None, None, None, None)
+        if need_grad and len(hooks) > 4 and hooks[4] is not None:
+            hooks[4]()
         if not hasattr(net, "_segk_zero_grads"):
             net._segk_zero_grads = set()
         rt = net._runtime_cls(dict(zip(names, params)), dict(net.named_buffers()), dtype, x.device, net.training, need_grad,

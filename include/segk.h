@@ -67,10 +67,13 @@ int segk_dice_focal_fwd(const void* logits, int logits_dtype, const int64_t* lab
  * loops, harnesses that forbid hipMalloc): identical arguments and results, but the block partials go to a fixed
  * 1 MiB device array inside the library instead of a caller-provided workspace, and the call makes no hipMalloc /
  * hipFree (nor any other allocating call).  No counterpart in the reference.
- * Limit: segk_dice_focal_workspace(N, C, HW) <= 1048576 bytes (e.g. up to 2978 images of 4 classes at 384 x 384),
- * larger shapes return SEGK_EWORKSPACE.  Every GPU the library runs on holds its own copy of the array until the
- * process ends; all calls on one GPU share it, so calls that overlap on one GPU (different streams or threads) race --
- * serialise them, or use segk_dice_focal_fwd.  Nothing in the array has to be cleared between calls.          */
+ * Limit: segk_dice_focal_workspace(N, C, HW) <= 1048576 bytes (the query is the bound: it grows with the number of
+ * blocks the kernel splits an image into, not only with N * C), larger shapes return SEGK_EWORKSPACE.  Every GPU the
+ * library runs on holds its own copy of the array until the process ends; all calls on one GPU share it, so calls that
+ * overlap on one GPU (different streams or threads) race -- serialise them, or use segk_dice_focal_fwd.  Nothing in the
+ * array has to be cleared between calls.
+ * The FIRST call on a device looks the array's address up (hipGetSymbolAddress, which may load the code object): make
+ * one warm-up call per device outside any stream capture; every later call only launches kernels and can be captured. */
 int segk_dice_focal_fwd_static(const void* logits, int logits_dtype, const int64_t* labels, const float* hot,
                                int64_t N, int64_t C, int64_t HW, float gamma, const float* alpha, int flags,
                                float* out_sums, int32_t* out_flags, float* focal_map, int dev, void* stream);

@@ -59,6 +59,6 @@ for name, H, Cin, Cout in LAYERS:
     totf += fl
     if os.environ.get("CHECK"):      # checksums of the results (compare two builds / modes on identical inputs)
         torch.cuda.synchronize()
-        line += f" sum|y| {float(y.buf.float().abs().sum()):.6e} sum|dx| {float(dx.buf.float().abs().sum()):.6e}"
+        line += f" sum|y| {float(y.buf.float().abs().sum()):.6e} sum|dx| {float(dx.buf.float().abs().sum()):.6e} sum|dw| {float(dw.abs().sum()):.6e}"
     print(line, flush=True)
 print("TOTAL", {k: f"{v:.2f} ms {totf/v/1e9:.0f} TF" for k, v in tot.items()})

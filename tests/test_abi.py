@@ -87,6 +87,13 @@ def test_argument_validation_needs_no_gpu():
         _lib.call("segk_conv_first_norm", 2, 16, 1, 3, 16, 16, 16, None, 64, None, None, None, None, None, 0, 16, 64, None, 0, None)
     with pytest.raises(_lib.SegkError, match="SEGK_EWORKSPACE"):
         _lib.call("segk_conv_first_norm_bwd", 16, 1, 3, 16, 16, 16, None, 16, None, None, 16, 64, 16, None, None, 0, 16, 16, 0, None)
+    # a bias that is only 4-byte aligned is refused by the three first-layer entry points (their kernels read it 16 bytes at a time)
+    with pytest.raises(_lib.SegkError, match="bias must be 16-byte aligned"):
+        _lib.call("segk_conv_first_fwd", 16, 1, 3, 16, 16, 16, 20, 64, 16, BF16, 64, None, 0, 0, None)
+    with pytest.raises(_lib.SegkError, match="bias must be 16-byte aligned"):
+        _lib.call("segk_conv_first_norm", 1, 16, 1, 3, 16, 16, 16, 20, 64, None, None, None, None, None, 0, None, 0, 16, 0, None)
+    with pytest.raises(_lib.SegkError, match="bias must be 16-byte aligned"):
+        _lib.call("segk_conv_first_norm_bwd", 16, 1, 3, 16, 16, 16, 20, 16, None, None, 16, 64, 16, None, None, 0, 16, 1 << 30, 0, None)
     with pytest.raises(_lib.SegkError, match="pairs"):
         _lib.call("segk_norm_bwd_sums_finalize", 16, 4, 64, 16, 16, None, 0, None, 0, 0, None)
     assert _lib.query("segk_conv_first_norm_bwd_workspace", 32, 384, 384) > 512 * 64 * 32 * 4

@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(w0) for _ in range(world)]
     dist.all_gather(gathered, w0)
     assert torch.equal(gathered[0], gathered[1]), "initial weights were not broadcast from rank 0"
-    sink, alloc, begin, finish = net._segk_grad_hooks
+    sink, alloc, begin, finish = net._segk_grad_hooks[:4]
     names = [n for n, _ in net.named_parameters()]
     local = {}
     for step in range(2):                              # two backward passes: bucket state must reset
@@ -117,7 +117,7 @@ def _wrapper_worker(rank, world, port, q):
     # autograd runs the two tapes' backward passes one after the other: right first (it was used last), then left
     for sub_name in ("right", "left"):
         sub = getattr(net, sub_name)
-        sink, alloc, begin, finish = sub._segk_grad_hooks
+        sink, alloc, begin, finish = sub._segk_grad_hooks[:4]
         begin()
         g = torch.Generator().manual_seed(31 * rank + len(sub_name))
         for n, p in reversed(list(sub.named_parameters())):
@@ -145,6 +145,101 @@ def test_flat_model_over_a_wrapper_world2():
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_wrapper_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert sorted(q.get(timeout=5)[0] for _ in range(2)) == [0, 1]
+
+
+class _TapeStandIn(torch.autograd.Function):
+    """What segk.net._TapeFn does with the hooks of a data-parallel wrapper, on CPU tensors: the forward is the module's
+    plain torch path, the backward produces every parameter gradient through alloc/sink between begin() and finish()."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        hooks = net._segk_grad_hooks
+        hooks[4]()
+        with torch.enable_grad():
+            xin = x.detach()
+            out = net._forward_host(xin)
+        ctx.net, ctx.out, ctx.hooks = net, out, hooks
+        return out.detach()
+
+    @staticmethod
+    def backward(ctx, dout):
+        sink, alloc, begin, finish = ctx.hooks[:4]
+        begin()
+        named = [(n, p) for n, p in ctx.net.named_parameters()]
+        grads = torch.autograd.grad(ctx.out, [p for _, p in named if p.requires_grad], dout)
+        by_name = dict(zip([n for n, p in named if p.requires_grad], grads))
+        for n, p in reversed(named):                       # backward completion order
+            if p.requires_grad:
+                buf = alloc(n, p)
+                buf.copy_(by_name[n])
+                sink(n, buf)
+        finish()
+        return (None, None) + tuple(None for _ in named)
+
+
+def _partial_worker(rank, world, port, q):
+    """Three tape networks under one wrapper: one fully frozen (records no backward), one used, one whose output never
+    reaches the loss (its backward is never called).  The pass must still close: used gradients averaged, unused zero."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "image-segmentation_amd"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from models.unetplusplus import conv_block_nested
+    from segk.flat import FlatModel
+
+    class Three(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.frozen = conv_block_nested(8, 8, 8)
+            self.used = conv_block_nested(8, 8, 8)
+            self.unused = conv_block_nested(8, 8, 8)
+
+    torch.manual_seed(3)
+    net = Three().train()
+    for p in net.frozen.parameters():
+        p.requires_grad_(False)
+    flat = FlatModel(net, bucket_mb=0.0005)
+    assert flat._ntargets == 2                               # the frozen network is not waited for
+    run = lambda sub, x: _TapeStandIn.apply(sub, x, *sub.parameters())
+    for step in range(3):
+        g = torch.Generator().manual_seed(17 * step + rank)
+        x = torch.randn(2, 8, 6, 6, generator=g)
+        if step == 1:                                        # a backward pass cut short by an exception left the state open:
+            flat._begin()                                    # the next forward must start a clean step
+            flat._queued = True
+            assert flat._open
+        with torch.no_grad():
+            h = net.frozen._forward_host(x)                  # need_grad is False: no tape, no backward node
+        y = run(net.used, h)
+        _ = run(net.unused, h)                               # forward only
+        for p in net.unused.parameters():
+            p.grad.fill_(123.0)                              # stale values that the pass must overwrite with zeros
+        y.square().mean().backward()
+        assert not flat._open and sorted(flat.buckets.launched) == list(range(len(flat.buckets.ranges))), step
+        for n, p in net.unused.named_parameters():
+            assert torch.count_nonzero(p.grad) == 0, (step, n)
+        for n, p in net.used.named_parameters():
+            mine = p.grad.clone()
+            both = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(both, mine)
+            assert torch.equal(both[0], both[1]), (step, n)  # every rank holds the same averaged gradient
+            assert torch.count_nonzero(mine) > 0 or "conv" in n and "bias" in n, (step, n)
+    q.put((rank, "ok"))
+    dist.destroy_process_group()
+
+
+def test_flat_model_closes_the_pass_when_networks_are_frozen_or_unused():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_partial_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
