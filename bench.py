@@ -311,6 +311,7 @@ def main():
     for i in range(args.steps):
         sample = timer is not None and i % 4 == 0
         ops.CONV_TIMER = timer if sample else None
+        ops.STREAM_TIMING = i % 8 == 0                    # the HBM-bound passes on every second event-timed step only
         engine._WGRAD_STREAM = overlap and not sample     # two convolutions sharing the GPU would stretch each other's event times
         timed_steps += int(sample)
         loss = step()
@@ -378,22 +379,39 @@ def main():
                        "value_if_h2d_not_overlapped": round(world * args.batch * args.steps / (elapsed + args.steps * h2d_ms / 1e3), 2)},
         }
         if timer:
-            fwd = sum(a.elapsed_time(b) for k, a, b, *_ in timer if k == "conv_fwd")
-            wg = sum(a.elapsed_time(b) for k, a, b, *_ in timer if k == "conv_wgrad")
+            # What a pair of event markers costs by itself: the elapsed time of pairs with NOTHING between them, on the same
+            # stream.  Every convolution launch of the event-timed steps is bracketed by such a pair, so its reading is the
+            # kernel's duration plus this much marker latency; the roofline uses the durations with it taken off and reports
+            # the raw sum next to them (the rocprofv3 kernel durations under profiles/ are the cross-check).
+            pairs = []
+            for _ in range(200):
+                m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                m0.record()
+                m1.record()
+                pairs.append((m0, m1))
+            torch.cuda.synchronize()
+            marker_ms = sorted(m0.elapsed_time(m1) for m0, m1 in pairs)[len(pairs) // 2]
+            streams = [(variant, max(a.elapsed_time(b) - marker_ms, 0.0), nbytes) for k, a, b, nbytes, variant, _ in timer if k == "stream"]
+            timer = [r for r in timer if r[0] != "stream"]
+            raw = [(k, a.elapsed_time(b), fl, variant, desc) for k, a, b, fl, variant, desc in timer]
+            dur = [(k, max(ms_ - marker_ms, 0.0), fl, variant, desc) for k, ms_, fl, variant, desc in raw]
+            raw_ms = sum(ms_ for _, ms_, *_ in raw) / timed_steps
+            fwd = sum(ms_ for k, ms_, *_ in dur if k == "conv_fwd")
+            wg = sum(ms_ for k, ms_, *_ in dur if k == "conv_wgrad")
             # the same events per kernel family, with the FLOP each launch actually multiplied (the 27-value patch row of the
             # first convolution counts as its 32 stored channels, so the sum is 0.1 % above the algorithmic figure)
             fam = {}
-            for k, a, b, fl, variant, _ in timer:
+            for k, t_, fl, variant, _ in dur:
                 name = "conv_wgrad_kernel" if k == "conv_wgrad" else f"conv_fwd_kernel[{variant}]"
                 ms_, fl_, n_ = fam.get(name, (0.0, 0.0, 0))
-                fam[name] = (ms_ + a.elapsed_time(b), fl_ + fl, n_ + 1)
+                fam[name] = (ms_ + t_, fl_ + fl, n_ + 1)
             conv_ms = (fwd + wg) / timed_steps
             if args.launch_table:
                 per = len(timer) // timed_steps
                 rows = []
                 for i in range(per):
                     k, _, _, fl, variant, desc = timer[i]
-                    us = [1e3 * timer[s_ * per + i][1].elapsed_time(timer[s_ * per + i][2]) for s_ in range(timed_steps)]
+                    us = [1e3 * dur[s_ * per + i][1] for s_ in range(timed_steps)]
                     rows.append({"i": i, "kind": k, "variant": variant, "shape": desc, "gflop": round(fl / 1e9, 2),
                                  "us_mean": round(sum(us) / len(us), 1), "us_min": round(min(us), 1), "us_max": round(max(us), 1)})
                 with open(args.launch_table, "w") as f:
@@ -414,12 +432,26 @@ def main():
                                                 f"algorithmic minimum {ALGO_CONV_GB_PER_STEP} GB") if traffic else None,
                                "kernel": "conv_fwd_kernel + conv_wgrad_kernel (all MFMA convolution launches of a step)",
                                "launches_per_step": len(timer) // timed_steps, "conv_ms_per_step": round(conv_ms, 3),
+                               "conv_ms_per_step_raw_events": round(raw_ms, 3), "event_marker_pair_us": round(1e3 * marker_ms, 2),
                                "event_timed_steps": timed_steps,
                                "fwd_dgrad_ms": round(fwd / timed_steps, 3), "wgrad_ms": round(wg / timed_steps, 3),
                                "whole_step_mfma_frac": round(gflop * args.batch / ms / peak, 4),
                                "by_kernel": {name: {"launches_per_step": n_ // timed_steps, "ms_per_step": round(ms_ / timed_steps, 3),
                                                     "achieved": round(fl_ / ms_ / 1e9, 1), "frac": round(fl_ / ms_ / 1e9 / peak, 4)}
                                              for name, (ms_, fl_, n_) in sorted(fam.items()) if ms_ > 0}}
+            # the HBM-bound passes of the same event-timed steps: algorithmic bytes / event-timed duration, by family
+            HBM_PEAK_GBS = 8000.0
+            sfam = {}
+            for name, ms_, nbytes in streams:
+                t_, b_, n_ = sfam.get(name, (0.0, 0.0, 0))
+                sfam[name] = (t_ + ms_, b_ + nbytes, n_ + 1)
+            ssteps = len(range(0, args.steps, 8))
+            out["roofline"]["streams"] = {name: {"calls_per_step": n_ // ssteps, "ms_per_step": round(t_ / ssteps, 3),
+                                                 "algorithmic_gb_per_step": round(b_ / ssteps / 1e9, 3),
+                                                 "achieved_gbs": round(b_ / t_ / 1e6, 1), "frac_of_hbm_peak": round(b_ / t_ / 1e6 / HBM_PEAK_GBS, 4)}
+                                          for name, (t_, b_, n_) in sorted(sfam.items()) if t_ > 0}
+            out["roofline"]["streams_note"] = ("bound hbm, peak 8000 GB/s; a call is one pass family launch group (e.g. the two passes and the "
+                                               "finalize of a BatchNorm backward), HIP-event timed on the launch stream with the marker latency taken off")
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_detectmid(args.depth, args.side) if args.model == "detectmid" else cpu_baseline(n_classes)
             if args.model not in ("unetvgg", "detectmid"):

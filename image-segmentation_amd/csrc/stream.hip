@@ -9,14 +9,23 @@ namespace segk {
 
 constexpr int kThreads = 256;
 
-// experiment switch: non-temporal accesses in the normalisation passes
-#ifdef SEGK_STREAM_NT
-#define LD8S load8s
-#define ST8S store8s
-#else
-#define LD8S load8
-#define ST8S store8
+// Tensors far larger than the memory-side cache (256 MB) are swept with non-temporal accesses and four independent
+// 16-byte vectors in flight per lane: measured on this part, a 2-reads-1-write sweep of 604 MB buffers runs at 4.5-5.4 TB/s
+// with plain one-vector-at-a-time accesses and at 5.9-6.3 TB/s this way.  Smaller tensors keep plain accesses: their
+// consumer finds them in the memory-side cache, and non-temporal accesses cost 15-25 % there.
+constexpr int64_t kBigTensorBytes = 200ll << 20;
+#ifndef SEGK_BWD_U
+#define SEGK_BWD_U 2
 #endif
+constexpr int kBwdRowsInFlight = SEGK_BWD_U;   // row groups per trip in the backward passes of big tensors
+template <typename T, bool NT> __device__ __forceinline__ void ld8(const T* p, float (&v)[8]) {
+    if constexpr (NT) Elem<T>::load8s(p, v);
+    else Elem<T>::load8(p, v);
+}
+template <typename T, bool NT> __device__ __forceinline__ void st8(T* p, const float (&v)[8]) {
+    if constexpr (NT) Elem<T>::store8s(p, v);
+    else Elem<T>::store8(p, v);
+}
 
 static inline int grid_for(int64_t items, int cap = 8192) {
     int64_t g = (items + kThreads - 1) / kThreads;
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(kThreads) void colsum_finalize_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------ normalise (+ReLU)
-template <typename T>
+template <typename T, bool BIG>
 __global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restrict__ x, int64_t ldx, int64_t M, int C,
                                                               const float* __restrict__ stats,
                                                               const float* __restrict__ gamma,
@@ -228,13 +237,34 @@ __global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restric
     const T* xb = x + (int64_t)g * M * ldx + v * 8;
     T* yb = y + (int64_t)g * M * ldy + v * 8;
     if (r >= rows) return;
+    if constexpr (BIG) {
+        // a block sweeps 4*rows consecutive pixels per trip: four vectors in flight per lane, 4 x 4 KB contiguous per block
+        const int64_t chunk = (int64_t)rows * 4;
+        for (int64_t base = (int64_t)blockIdx.x * chunk + r; base < M; base += (int64_t)gridDim.x * chunk) {
+            float a[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (base + u * rows < M) ld8<T, true>(xb + (base + u * rows) * ldx, a[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (base + u * rows >= M) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a[u][j] = a[u][j] * sc[j] + sh[j];
+                    if (relu) a[u][j] = fmaxf(a[u][j], 0.f);
+                }
+                st8<T, true>(yb + (base + u * rows) * ldy, a[u]);
+            }
+        }
+        return;
+    }
     // four rows per trip, all loads issued before the first use: more bytes in flight per wave
     const int64_t step = (int64_t)gridDim.x * rows;
     int64_t p = (int64_t)blockIdx.x * rows + r;
     for (; p + 3 * step < M; p += 4 * step) {
         float a[4][8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) Elem<T>::LD8S(xb + (p + u * step) * ldx, a[u]);
+        for (int u = 0; u < 4; ++u) ld8<T, BIG>(xb + (p + u * step) * ldx, a[u]);
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -242,23 +272,23 @@ __global__ __launch_bounds__(kThreads) void norm_apply_kernel(const T* __restric
                 a[u][j] = a[u][j] * sc[j] + sh[j];
                 if (relu) a[u][j] = fmaxf(a[u][j], 0.f);
             }
-            Elem<T>::ST8S(yb + (p + u * step) * ldy, a[u]);
+            st8<T, BIG>(yb + (p + u * step) * ldy, a[u]);
         }
     }
     for (; p < M; p += step) {
         float a[8];
-        Elem<T>::LD8S(xb + p * ldx, a);
+        ld8<T, BIG>(xb + p * ldx, a);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             a[j] = a[j] * sc[j] + sh[j];
             if (relu) a[j] = fmaxf(a[j], 0.f);
         }
-        Elem<T>::ST8S(yb + p * ldy, a);
+        st8<T, BIG>(yb + p * ldy, a);
     }
 }
 
 // backward, pass 1: per block  s1 = sum g, s2 = sum g*xhat   (g = dy masked by the ReLU of the forward)
-template <typename T>
+template <typename T, bool BIG>
 __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __restrict__ dy, int64_t ld_dy,
                                                                     const T* __restrict__ x, int64_t ldx, int64_t M, int C,
                                                                     const float* __restrict__ stats,
@@ -285,10 +315,7 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __r
     float s1[8], s2[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
-    for (int64_t p = lo + r; p < hi && r < rows; p += rows) {   // r >= rows: spare threads when C/8 does not divide the block
-        float a[8], d[8];
-        Elem<T>::LD8S(xb + p * ldx, a);
-        Elem<T>::LD8S(db + p * ld_dy, d);
+    auto add_row = [&](const float (&a)[8], const float (&d)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sc = rstd[j] * ga[j];
@@ -298,6 +325,27 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_partial_kernel(const T* __r
             s1[j] += gg;
             s2[j] += gg * xh;
         }
+    };
+    int64_t p = lo + r;
+    if constexpr (BIG) {
+        // U consecutive row groups per trip: 2*U vectors in flight per lane
+        constexpr int U = kBwdRowsInFlight;
+        for (; p + (U - 1) * rows < hi && r < rows; p += U * rows) {
+            float a[U][8], d[U][8];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                ld8<T, true>(xb + (p + u * rows) * ldx, a[u]);
+                ld8<T, true>(db + (p + u * rows) * ld_dy, d[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) add_row(a[u], d[u]);
+        }
+    }
+    for (; p < hi && r < rows; p += rows) {   // r >= rows: spare threads when C/8 does not divide the block
+        float a[8], d[8];
+        ld8<T, BIG>(xb + p * ldx, a);
+        ld8<T, BIG>(db + p * ld_dy, d);
+        add_row(a, d);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[threadIdx.x][j] = s1[j]; red[threadIdx.x][8 + j] = s2[j]; }
@@ -329,7 +377,7 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_finalize_kernel(const float
 }
 
 // pass 2: dx = gamma*rstd*(g - s1/M - xhat*s2/M)     (frozen: dx = gamma*rstd*g)
-template <typename T>
+template <typename T, bool BIG>
 __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restrict__ dy, int64_t ld_dy,
                                                                const T* __restrict__ x, int64_t ldx, int64_t M, int C,
                                                                const float* __restrict__ stats,
@@ -355,10 +403,7 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
     const T* xb = x + (int64_t)g * M * ldx + v * 8;
     const T* db = dy + (int64_t)g * M * ld_dy + v * 8;
     T* ob = dx + (int64_t)g * M * ld_dx + v * 8;
-    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M && r < rows; p += (int64_t)gridDim.x * rows) {
-        float a[8], d[8];
-        Elem<T>::LD8S(xb + p * ldx, a);
-        Elem<T>::LD8S(db + p * ld_dy, d);
+    auto row = [&](const float (&a)[8], float (&d)[8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float sc = rstd[j] * ga[j];
@@ -367,13 +412,46 @@ __global__ __launch_bounds__(kThreads) void norm_bwd_dx_kernel(const T* __restri
             const float gg = (relu && !(pre > 0.f)) ? 0.f : d[j];
             d[j] = sc * (gg - m1[j] - xh * m2[j]);
         }
+    };
+    if constexpr (BIG) {
+        if (r >= rows) return;
+        // a block sweeps U*rows consecutive pixels per trip: 2*U (3*U with add_dx) vectors in flight per lane
+        constexpr int U = kBwdRowsInFlight;
+        const int64_t chunk = (int64_t)rows * U;
+        for (int64_t base = (int64_t)blockIdx.x * chunk + r; base < M; base += (int64_t)gridDim.x * chunk) {
+            float a[U][8], d[U][8], o[U][8];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + u * rows >= M) continue;
+                ld8<T, true>(xb + (base + u * rows) * ldx, a[u]);
+                ld8<T, true>(db + (base + u * rows) * ld_dy, d[u]);
+                if (add_dx) ld8<T, true>(ob + (base + u * rows) * ld_dx, o[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (base + u * rows >= M) continue;
+                row(a[u], d[u]);
+                if (add_dx) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) d[u][j] += o[u][j];
+                }
+                st8<T, true>(ob + (base + u * rows) * ld_dx, d[u]);
+            }
+        }
+        return;
+    }
+    for (int64_t p = (int64_t)blockIdx.x * rows + r; p < M && r < rows; p += (int64_t)gridDim.x * rows) {
+        float a[8], d[8];
+        ld8<T, BIG>(xb + p * ldx, a);
+        ld8<T, BIG>(db + p * ld_dy, d);
+        row(a, d);
         if (add_dx) {
             float o[8];
-            Elem<T>::LD8S(ob + p * ld_dx, o);
+            ld8<T, BIG>(ob + p * ld_dx, o);
 #pragma unroll
             for (int j = 0; j < 8; ++j) d[j] += o[j];
         }
-        Elem<T>::ST8S(ob + p * ld_dx, d);
+        st8<T, BIG>(ob + p * ld_dx, d);
     }
 }
 
@@ -393,7 +471,7 @@ __device__ __forceinline__ int64_t window_pixel(int64_t q, int H, int W) {
     return (n * H + 2 * oy) * W + 2 * ox;
 }
 
-template <typename T>
+template <typename T, bool BIG>
 __global__ __launch_bounds__(kThreads) void norm_pool_apply_kernel(const T* __restrict__ x, int64_t ldx, int64_t Q, int H, int W,
                                                                    int C, const float* __restrict__ stats,
                                                                    const float* __restrict__ gamma,
@@ -414,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void norm_pool_apply_kernel(const T* __re
         const int64_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
         float a[4][8], m[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) Elem<T>::LD8S(x + off[k] * ldx + v * 8, a[k]);
+        for (int k = 0; k < 4; ++k) ld8<T, BIG>(x + off[k] * ldx + v * 8, a[k]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -422,25 +500,25 @@ __global__ __launch_bounds__(kThreads) void norm_pool_apply_kernel(const T* __re
                 a[k][j] = fmaxf(a[k][j] * sc[j] + sh[j], 0.f);
                 m[j] = k == 0 ? a[k][j] : fmaxf(m[j], a[k][j]);
             }
-            Elem<T>::ST8S(y + off[k] * ldy + v * 8, a[k]);
+            st8<T, BIG>(y + off[k] * ldy + v * 8, a[k]);
         }
-        Elem<T>::ST8S(pool + q * ldp + v * 8, m);
+        st8<T, BIG>(pool + q * ldp + v * 8, m);
     }
 }
 
 // gradient reaching the norm output at the four pixels of window q (masked by the ReLU), and the normalised inputs
-template <typename T>
+template <typename T, bool BIG>
 __device__ __forceinline__ void window_grad(const T* __restrict__ da, int64_t ld_da, const T* __restrict__ dp, int64_t ld_dp,
                                             const T* __restrict__ x, int64_t ldx, int64_t q, const int64_t (&off)[4], int v,
                                             const float (&mean)[8], const float (&rstd)[8], const float (&ga)[8],
                                             const float (&be)[8], float (&g)[4][8], float (&xh)[4][8]) {
     float pre[4][8], gp[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) Elem<T>::LD8S(x + off[k] * ldx + v * 8, pre[k]);
-    Elem<T>::LD8S(dp + q * ld_dp + v * 8, gp);
+    for (int k = 0; k < 4; ++k) ld8<T, BIG>(x + off[k] * ldx + v * 8, pre[k]);
+    ld8<T, BIG>(dp + q * ld_dp + v * 8, gp);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        if (da) Elem<T>::LD8S(da + off[k] * ld_da + v * 8, g[k]);
+        if (da) ld8<T, BIG>(da + off[k] * ld_da + v * 8, g[k]);
         else {
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[k][j] = 0.f;
@@ -466,7 +544,7 @@ __device__ __forceinline__ void window_grad(const T* __restrict__ da, int64_t ld
     }
 }
 
-template <typename T>
+template <typename T, bool BIG>
 __global__ __launch_bounds__(kThreads) void norm_pool_bwd_partial_kernel(const T* __restrict__ da, int64_t ld_da,
                                                                          const T* __restrict__ dp, int64_t ld_dp,
                                                                          const T* __restrict__ x, int64_t ldx, int64_t Q, int H,
@@ -496,7 +574,7 @@ __global__ __launch_bounds__(kThreads) void norm_pool_bwd_partial_kernel(const T
         const int64_t p00 = window_pixel(q, H, W);
         const int64_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
         float g[4][8], xh[4][8];
-        window_grad<T>(da, ld_da, dp, ld_dp, x, ldx, q, off, v, mean, rstd, ga, be, g, xh);
+        window_grad<T, BIG>(da, ld_da, dp, ld_dp, x, ldx, q, off, v, mean, rstd, ga, be, g, xh);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -513,7 +591,7 @@ __global__ __launch_bounds__(kThreads) void norm_pool_bwd_partial_kernel(const T
     }
 }
 
-template <typename T>
+template <typename T, bool BIG>
 __global__ __launch_bounds__(kThreads) void norm_pool_bwd_dx_kernel(const T* __restrict__ da, int64_t ld_da,
                                                                     const T* __restrict__ dp, int64_t ld_dp,
                                                                     const T* __restrict__ x, int64_t ldx, int64_t Q, int H, int W,
@@ -540,12 +618,12 @@ __global__ __launch_bounds__(kThreads) void norm_pool_bwd_dx_kernel(const T* __r
         const int64_t p00 = window_pixel(q, H, W);
         const int64_t off[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
         float g[4][8], xh[4][8];
-        window_grad<T>(da, ld_da, dp, ld_dp, x, ldx, q, off, v, mean, rstd, ga, be, g, xh);
+        window_grad<T, BIG>(da, ld_da, dp, ld_dp, x, ldx, q, off, v, mean, rstd, ga, be, g, xh);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) g[k][j] = rstd[j] * ga[j] * (g[k][j] - m1[j] - xh[k][j] * m2[j]);
-            Elem<T>::ST8S(dx + off[k] * ld_dx + v * 8, g[k]);
+            st8<T, BIG>(dx + off[k] * ld_dx + v * 8, g[k]);
         }
     }
 }
@@ -1306,6 +1384,18 @@ static int stats_bpg(int64_t groups, int64_t M, int64_t C) {
     return (int)bpg;
 }
 
+// whether a tensor of `elems` elements of `dtype` is swept with the big-tensor access pattern (SEGK_STREAM_BIG=0/1 forces it)
+static bool big_tensor(int64_t elems, int dtype) {
+    static const int forced = getenv("SEGK_STREAM_BIG") ? atoi(getenv("SEGK_STREAM_BIG")) : -1;
+    if (forced >= 0) return forced != 0;
+    return elems * (int64_t)esize(dtype) >= kBigTensorBytes;
+}
+#define SEGK_DISPATCH_BIG(flag, BIG, ...)                      \
+    do {                                                       \
+        if (flag) { constexpr bool BIG = true; __VA_ARGS__; }  \
+        else { constexpr bool BIG = false; __VA_ARGS__; }      \
+    } while (0)
+
 static int check_act(const char* who, const void* p, int64_t ld, int64_t C, int dtype) {
     if (!p) return fail(SEGK_EINVAL, "%s: null activation pointer", who);
     if (dtype != SEGK_F32 && dtype != SEGK_BF16) return fail(SEGK_EINVAL, "%s: unknown dtype %d", who, dtype);
@@ -1447,9 +1537,9 @@ extern "C" int segk_norm_apply(int dtype, const void* x, int64_t ldx, int64_t gr
     SEGK_USE_DEVICE(dev);
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(M, rows, groups);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_apply_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0,
+    SEGK_DISPATCH_BIG(big_tensor(groups * M * C, dtype), BIG, SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_apply_kernel<T, BIG>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)x, ldx, M, (int)C, stats, gamma, beta, flags & 1,
-                                                     (T*)y, ldy));
+                                                     (T*)y, ldy)));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1472,17 +1562,17 @@ extern "C" int segk_norm_bwd(int dtype, const void* dy, int64_t ld_dy, const voi
     const int relu = flags & 1, accumulate = (flags >> 1) & 1, frozen = (flags >> 2) & 1;
     float* part = (float*)workspace;
     float* red = (float*)((char*)workspace + align_up((size_t)groups * bpg * 2 * C * sizeof(float), 256));
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_partial_kernel<T>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
-                                                     (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, bpg, part));
+    SEGK_DISPATCH_BIG(big_tensor(groups * M * C, dtype), BIG, SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_partial_kernel<T, BIG>), dim3(bpg, (unsigned)groups), dim3(kThreads), 0, st,
+                                                     (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, bpg, part)));
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, (unsigned)groups), dim3(kThreads), 0, st,
                        (const float*)part, bpg, (int)C, red, dgamma, dbeta, accumulate, (int64_t)(2 * C));
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(M, rows, groups);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0, st,
+    SEGK_DISPATCH_BIG(big_tensor(groups * M * C, dtype), BIG, SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T, BIG>), dim3((unsigned)gx, (unsigned)groups), dim3(kThreads), 0, st,
                                                      (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, frozen,
-                                                     (const float*)red, (T*)dx, ld_dx, (flags >> 3) & 1));
+                                                     (const float*)red, (T*)dx, ld_dx, (flags >> 3) & 1)));
     SEGK_LAUNCH_CHECK();
     if (dbias_out) {
         // With batch statistics the gradient reaching the convolution in front of the norm sums to zero
@@ -1534,9 +1624,9 @@ extern "C" int segk_norm_bwd_finish(int dtype, const float* partials, int64_t ro
     SEGK_LAUNCH_CHECK();
     const int rws = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(M, rws, 1);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T>), dim3((unsigned)gx, 1), dim3(kThreads), 0, st,
+    SEGK_DISPATCH_BIG(big_tensor(M * C, dtype), BIG, SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_bwd_dx_kernel<T, BIG>), dim3((unsigned)gx, 1), dim3(kThreads), 0, st,
                                                      (const T*)dy, ld_dy, (const T*)x, ldx, M, (int)C, stats, gamma, beta, relu, 0,
-                                                     (const float*)red, (T*)dx, ld_dx, (flags >> 3) & 1));
+                                                     (const float*)red, (T*)dx, ld_dx, (flags >> 3) & 1)));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1583,9 +1673,9 @@ extern "C" int segk_norm_pool_apply(int dtype, const void* x, int64_t ldx, int64
     const int64_t Q = N * (H / 2) * (W / 2);
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(Q, rows, 1);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_apply_kernel<T>), dim3((unsigned)gx), dim3(kThreads), 0,
+    SEGK_DISPATCH_BIG(big_tensor(4 * Q * C, dtype), BIG, SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_apply_kernel<T, BIG>), dim3((unsigned)gx), dim3(kThreads), 0,
                                                      (hipStream_t)stream, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, stats, gamma, beta,
-                                                     (T*)y, ldy, (T*)pool, ld_pool));
+                                                     (T*)y, ldy, (T*)pool, ld_pool)));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }
@@ -1610,18 +1700,18 @@ extern "C" int segk_norm_pool_bwd(int dtype, const void* dy, int64_t ld_dy, cons
     const int accumulate = (flags >> 1) & 1, frozen = (flags >> 2) & 1;
     float* part = (float*)workspace;
     float* red = (float*)((char*)workspace + align_up((size_t)bpg * 2 * C * sizeof(float), 256));
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_bwd_partial_kernel<T>), dim3(bpg), dim3(kThreads), 0, st, (const T*)dy, ld_dy,
+    SEGK_DISPATCH_BIG(big_tensor(M * C, dtype), BIG, SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_bwd_partial_kernel<T, BIG>), dim3(bpg), dim3(kThreads), 0, st, (const T*)dy, ld_dy,
                                                      (const T*)dpool, ld_dpool, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, stats, gamma,
-                                                     beta, bpg, part));
+                                                     beta, bpg, part)));
     SEGK_LAUNCH_CHECK();
     hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((unsigned)C, 1), dim3(kThreads), 0, st, (const float*)part, bpg, (int)C,
                        red, dgamma, dbeta, accumulate, (int64_t)(2 * C));
     SEGK_LAUNCH_CHECK();
     const int rows = kThreads / (int)(C / 8);
     const int64_t gx = stream_blocks(Q, rows, 1);
-    SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_bwd_dx_kernel<T>), dim3((unsigned)gx), dim3(kThreads), 0, st, (const T*)dy,
+    SEGK_DISPATCH_BIG(big_tensor(M * C, dtype), BIG, SEGK_DISPATCH_DTYPE(dtype, T, hipLaunchKernelGGL((norm_pool_bwd_dx_kernel<T, BIG>), dim3((unsigned)gx), dim3(kThreads), 0, st, (const T*)dy,
                                                      ld_dy, (const T*)dpool, ld_dpool, (const T*)x, ldx, Q, (int)H, (int)W, (int)C, M, stats,
-                                                     gamma, beta, frozen, (const float*)red, (T*)dx, ld_dx));
+                                                     gamma, beta, frozen, (const float*)red, (T*)dx, ld_dx)));
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

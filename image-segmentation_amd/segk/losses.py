@@ -6,7 +6,7 @@ import weakref
 import torch
 import torch.nn.functional as F
 
-from . import _lib
+from . import _lib, ops
 from .ops import dt, workspace
 from ._lib import call, query
 
@@ -43,9 +43,11 @@ class _DiceFocalFn(torch.autograd.Function):
         fmap = torch.empty(z.shape, dtype=torch.float32, device=z.device) if want_map else None
         ws = workspace(query("segk_dice_focal_workspace", N, C, HW), z.device)
         p = lambda t: None if t is None else t.data_ptr()
-        call("segk_dice_focal_fwd", z.data_ptr(), dt(z.dtype), p(labels), p(hot), N, C, HW, float(gamma), p(al), flags,
-             sums.data_ptr(), iflags.data_ptr(), p(fmap), ws.data_ptr(), ws.numel(), dev, st)
-        call("segk_dice_focal_finalize", sums.data_ptr(), iflags.data_ptr(), N, C, HW, flags, scalars.data_ptr(), dev, st)
+        tbytes = 8 if labels is not None else 4 * C
+        with ops._streamed("dice + focal loss", N * HW * (C * z.element_size() + tbytes)):
+            call("segk_dice_focal_fwd", z.data_ptr(), dt(z.dtype), p(labels), p(hot), N, C, HW, float(gamma), p(al), flags,
+                 sums.data_ptr(), iflags.data_ptr(), p(fmap), ws.data_ptr(), ws.numel(), dev, st)
+            call("segk_dice_focal_finalize", sums.data_ptr(), iflags.data_ptr(), N, C, HW, flags, scalars.data_ptr(), dev, st)
         ctx.save_for_backward(z, labels if labels is not None else hot, sums, iflags, scalars)
         ctx.meta = (N, C, HW, float(gamma), al, flags, labels is not None, logits.dtype)
         ctx.token = _store().get("pending")      # set by dice_focal(): marks the shared node as spent once it has run backward
@@ -70,9 +72,10 @@ class _DiceFocalFn(torch.autograd.Function):
         dz = torch.empty_like(z)
         dev, st = _env(z)
         p = lambda t: None if t is None else t.data_ptr()
-        call("segk_dice_focal_bwd", z.data_ptr(), dt(z.dtype), p(tgt) if is_labels else None, None if is_labels else p(tgt),
-             N, C, HW, gamma, p(al), flags, sums.data_ptr(), iflags.data_ptr(), scalars.data_ptr(), gs.data_ptr(),
-             dz.data_ptr(), dev, st)
+        with ops._streamed("dice + focal loss", N * HW * (2 * C * z.element_size() + (8 if is_labels else 4 * C))):
+            call("segk_dice_focal_bwd", z.data_ptr(), dt(z.dtype), p(tgt) if is_labels else None, None if is_labels else p(tgt),
+                 N, C, HW, gamma, p(al), flags, sums.data_ptr(), iflags.data_ptr(), scalars.data_ptr(), gs.data_ptr(),
+                 dz.data_ptr(), dev, st)
         return dz.to(in_dtype), None, None, None, None, None
 
 

@@ -75,7 +75,8 @@ _workspaces = {}
 
 # Optional per-launch timing of the MFMA convolutions (bench.py's roofline leg): a list that receives
 # (kind, start_event, end_event, algorithmic FLOP, kernel variant, shape text) for every conv launch, recorded on the
-# stream the kernel runs on.
+# stream the kernel runs on.  The HBM-bound passes (normalisation, up-sampling, loss) are recorded the same way with kind
+# "stream", their algorithmic bytes in place of the FLOP and their family name as the variant.
 CONV_TIMER = None
 
 
@@ -93,6 +94,13 @@ class _Timed:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             CONV_TIMER.append((self.kind, self.e0, e1, self.flops, self.variant, self.desc))
+
+
+STREAM_TIMING = True     # with CONV_TIMER set: also record the HBM-bound passes (bench.py turns it on for a few steps only)
+
+
+def _streamed(family, nbytes, desc=""):
+    return _Timed("stream", float(nbytes), family, desc) if (CONV_TIMER is not None and STREAM_TIMING) else contextlib.nullcontext()
 
 
 def workspace(nbytes, device):
@@ -384,8 +392,9 @@ def norm_stats(x, groups, eps, stats, running_mean=None, running_var=None, momen
     M = x.P // groups
     dev, st = _env(x.buf)
     ws = workspace(query("segk_norm_workspace", groups, M, x.C), x.device)
-    call("segk_norm_stats", dt(x.dtype), x.ptr, x.ld, groups, M, x.C, eps, stats.data_ptr(), _p(running_mean),
-         _p(running_var), momentum, ws.data_ptr(), ws.numel(), dev, st)
+    with _streamed("norm statistics", x.P * x.C * x.buf.element_size()):
+        call("segk_norm_stats", dt(x.dtype), x.ptr, x.ld, groups, M, x.C, eps, stats.data_ptr(), _p(running_mean),
+             _p(running_var), momentum, ws.data_ptr(), ws.numel(), dev, st)
     return stats
 
 
@@ -399,8 +408,9 @@ def norm_eval_stats(running_mean, running_var, eps, stats):
 def norm_apply(x, groups, stats, gamma, beta, relu, out):
     M = x.P // groups
     dev, st = _env(x.buf)
-    call("segk_norm_apply", dt(x.dtype), x.ptr, x.ld, groups, M, x.C, stats.data_ptr(), _p(gamma), _p(beta),
-         RELU if relu else 0, out.ptr, out.ld, dev, st)
+    with _streamed("norm forward", 2 * x.P * x.C * x.buf.element_size()):
+        call("segk_norm_apply", dt(x.dtype), x.ptr, x.ld, groups, M, x.C, stats.data_ptr(), _p(gamma), _p(beta),
+             RELU if relu else 0, out.ptr, out.ld, dev, st)
     return out
 
 
@@ -411,16 +421,19 @@ def norm_bwd(dy, x, groups, stats, gamma, beta, relu, dx, dgamma=None, dbeta=Non
     dev, st = _env(x.buf)
     ws = workspace(query("segk_norm_workspace", groups, M, x.C), x.device)
     flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (FROZEN if frozen else 0) | (8 if add_dx else 0)
-    call("segk_norm_bwd", dt(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, groups, M, x.C, stats.data_ptr(), _p(gamma), _p(beta),
-         flags, dx.ptr, dx.ld, _p(dgamma), _p(dbeta), _p(dbias), ws.data_ptr(), ws.numel(), dev, st)
+    # two passes over (dy, x), one result written (read first when it is added to)
+    with _streamed("norm backward", (6 if add_dx else 5) * x.P * x.C * x.buf.element_size()):
+        call("segk_norm_bwd", dt(x.dtype), dy.ptr, dy.ld, x.ptr, x.ld, groups, M, x.C, stats.data_ptr(), _p(gamma), _p(beta),
+             flags, dx.ptr, dx.ld, _p(dgamma), _p(dbeta), _p(dbias), ws.data_ptr(), ws.numel(), dev, st)
     return dx
 
 
 def norm_pool_apply(x, stats, gamma, beta, out, pool):
     """out = relu(batchnorm(x)), pool = maxpool2x2(out) in one pass."""
     dev, st = _env(x.buf)
-    call("segk_norm_pool_apply", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, stats.data_ptr(), _p(gamma), _p(beta),
-         out.ptr, out.ld, pool.ptr, pool.ld, dev, st)
+    with _streamed("norm forward", 2.25 * x.P * x.C * x.buf.element_size()):
+        call("segk_norm_pool_apply", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, stats.data_ptr(), _p(gamma), _p(beta),
+             out.ptr, out.ld, pool.ptr, pool.ld, dev, st)
     return out, pool
 
 
@@ -429,9 +442,11 @@ def norm_pool_bwd(dy, dpool, x, stats, gamma, beta, dx, dgamma=None, dbeta=None,
     dev, st = _env(x.buf)
     ws = workspace(query("segk_norm_workspace", 1, x.P, x.C), x.device)
     flags = (ACCUM if accumulate else 0) | (FROZEN if frozen else 0)
-    call("segk_norm_pool_bwd", dt(x.dtype), dy.ptr if dy is not None else None, dy.ld if dy is not None else 0, dpool.ptr,
-         dpool.ld, x.ptr, x.ld, x.N, x.H, x.W, x.C, stats.data_ptr(), _p(gamma), _p(beta), flags, dx.ptr, dx.ld, _p(dgamma),
-         _p(dbeta), ws.data_ptr(), ws.numel(), dev, st)
+    # two passes over (x, pooled gradient [, skip gradient]), one result written
+    with _streamed("norm backward", ((5.5 if dy is not None else 3.5)) * x.P * x.C * x.buf.element_size()):
+        call("segk_norm_pool_bwd", dt(x.dtype), dy.ptr if dy is not None else None, dy.ld if dy is not None else 0, dpool.ptr,
+             dpool.ld, x.ptr, x.ld, x.N, x.H, x.W, x.C, stats.data_ptr(), _p(gamma), _p(beta), flags, dx.ptr, dx.ld, _p(dgamma),
+             _p(dbeta), ws.data_ptr(), ws.numel(), dev, st)
     return dx
 
 
@@ -451,16 +466,18 @@ def maxpool_bwd(x, dy, dx, accumulate=False):
 
 def upsample_fwd(x, out, stats=None, relu=False, align=False):
     dev, st = _env(x.buf)
-    call("segk_upsample2x_fwd", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, _p(stats),
-         (RELU if relu else 0) | (ALIGN if align else 0), out.ptr, out.ld, dev, st)
+    with _streamed("bilinear x2", 5 * x.P * x.C * x.buf.element_size()):
+        call("segk_upsample2x_fwd", dt(x.dtype), x.ptr, x.ld, x.N, x.H, x.W, x.C, _p(stats),
+             (RELU if relu else 0) | (ALIGN if align else 0), out.ptr, out.ld, dev, st)
     return out
 
 
 def upsample_bwd(dy, y, dx, relu=False, align=False):
     """dx has the low-resolution shape; y is the saved forward output (only read when relu)."""
     dev, st = _env(dy.buf)
-    call("segk_upsample2x_bwd", dt(dy.dtype), dy.ptr, dy.ld, y.ptr if y is not None else None, y.ld if y is not None else 0,
-         dx.N, dx.H, dx.W, dx.C, (RELU if relu else 0) | (ALIGN if align else 0), dx.ptr, dx.ld, dev, st)
+    with _streamed("bilinear x2", 5 * dx.P * dx.C * dx.buf.element_size()):
+        call("segk_upsample2x_bwd", dt(dy.dtype), dy.ptr, dy.ld, y.ptr if y is not None else None, y.ld if y is not None else 0,
+             dx.N, dx.H, dx.W, dx.C, (RELU if relu else 0) | (ALIGN if align else 0), dx.ptr, dx.ld, dev, st)
     return dx
 
 
