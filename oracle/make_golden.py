@@ -445,6 +445,11 @@ def main():
         if "--misc-losses-only" in partial:
             golden_misc_losses(ref, pin)
     else:
+        # a full run rewrites every check of its own; checks that other generator scripts recorded in the same file
+        # (oracle/make_golden_wellcond.py: "model/wellcond*", oracle/run_reference_callers.py) are carried over
+        pf = os.path.join(GOLD, "oracle_pin.json")
+        if os.path.exists(pf):
+            pin = {k: v for k, v in json.load(open(pf)).get("checks", {}).items() if k.startswith(("model/wellcond", "callers/"))}
         golden_losses(ref, pin)
         golden_aux_losses(ref, pin)
         golden_edge_losses(pin)

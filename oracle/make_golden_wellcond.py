@@ -1,4 +1,4 @@
-"""tests/golden/wellcond.npz: one training step of the REFERENCE's UNetVgg on the well-conditioned cases of
+"""tests/golden/wellcond.npz: one training step of the REFERENCE's UNetVgg (bilinear and transposed-convolution decoder) and Nested_UNet on the well-conditioned cases of
 oracle/wellcond.py, with every parameter gradient summarised so that the whole tensor is pinned in a few KB:
 its norm, 4096 strided samples and four +-1 hash projections.  Also pins the oracle restatement bit for bit on
 these cases (tests/golden/oracle_pin.json).  Build container only (needs /root/reference):
@@ -39,14 +39,16 @@ def summary(name, g):
 def main():
     import importlib
     uv = importlib.import_module("models.unetvgg")
+    upp = importlib.import_module("models.unetplusplus")
     dice = importlib.import_module("loss.dice")
     focal = importlib.import_module("loss.focal")
-    assert uv.__file__.startswith("/root/reference")
+    assert uv.__file__.startswith("/root/reference") and upp.__file__.startswith("/root/reference")
     out, pin = {}, {}
-    for tag in WC.TAGS:
+    for tag, (kind, kw, _) in WC.CASES.items():
         x, t = WC.batch(tag)
-        m_ref = WC.condition_(RM.hash_init_(uv.UNetVgg(out_classes=4))).train()
-        m_or = WC.condition_(RM.hash_init_(RM.RefUNetVgg(out_classes=4))).train()
+        ref_net = uv.UNetVgg(out_classes=4, **kw) if kind == "unetvgg" else upp.Nested_UNet(in_ch=1, out_ch=4)
+        m_ref = WC.condition_(RM.hash_init_(ref_net)).train()
+        m_or = WC.oracle_model(tag)
         la = m_ref(x)
         lossa = dice.dice_loss_sq(la, t) + focal.focal_loss_with_logits(la, t)
         lossa.backward()
@@ -57,7 +59,7 @@ def main():
         for (k, p), (_, q) in zip(m_ref.named_parameters(), m_or.named_parameters()):
             same = same and torch.equal(p.grad, q.grad)
         pin[f"model/{tag}"] = bool(same)
-        m64 = WC.condition_(RM.hash_init_(RM.RefUNetVgg(out_classes=4))).double().train()
+        m64 = WC.oracle_model(tag).double()
         l64 = m64(x.double())
         (RL.dice_loss_sq(l64, t) + RL.focal_loss_with_logits(l64, t)).backward()
         worst = max(float((p.grad.double() - q.grad).norm() / q.grad.norm()) for (_, p), (_, q) in

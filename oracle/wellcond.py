@@ -1,4 +1,4 @@
-"""A well-conditioned UNetVgg case for end-to-end GRADIENT parity (test infrastructure, like the rest of oracle/).
+"""Well-conditioned UNetVgg / UNet++ cases for end-to-end GRADIENT parity (test infrastructure, like the rest of oracle/).
 
 On a random-weight network the fp32 gradients of ANY implementation, the reference's included, sit 1e-3..1e-2 from exact
 arithmetic: a handful of pre-ReLU values lie within rounding of zero, their sign (the ReLU mask) differs between two
@@ -11,6 +11,37 @@ import torch
 from . import ref_models as RM
 
 TAGS = ("wellcond:8", "wellcond:7")      # chosen among twelve candidates: the two with no value within rounding of a ReLU threshold
+
+# tag -> (network, constructor arguments, input channels).  The transposed-convolution decoder (models/unetvgg.py:31-32) and
+# UNet++ (models/unetplusplus.py:27-82) were each picked among twelve candidate batches as well: the transposed-convolution
+# case for the smallest reference-fp32-to-fp64 gradient distance with the fewest values near a threshold; for UNet++ every
+# candidate leaves the REFERENCE's own fp32 gradients about 1e-4 from exact arithmetic on two tensors (conv0_4.bn1.bias,
+# conv0_4.conv2.weight: sums that cancel), everything else being below 3e-5 -- the fixture records that distance.
+CASES = {
+    "wellcond:8": ("unetvgg", {}, 3),
+    "wellcond:7": ("unetvgg", {}, 3),
+    "wellcond-convtrans:5": ("unetvgg", {"if_convtrans": True}, 3),
+    "wellcond-unetpp:8": ("unetpp", {}, 1),
+}
+
+
+def oracle_model(tag):
+    """The conditioned CPU oracle network of case `tag` (fp32, training mode)."""
+    kind, kw, _ = CASES[tag]
+    m = RM.RefUNetVgg(out_classes=4, **kw) if kind == "unetvgg" else RM.RefNestedUNet(in_ch=1, out_ch=4)
+    return condition_(RM.hash_init_(m)).train()
+
+
+def hip_model(tag):
+    """The conditioned network of case `tag` built from the product modules (CPU tensors; the caller moves it)."""
+    kind, kw, _ = CASES[tag]
+    if kind == "unetvgg":
+        from models.unetvgg import UNetVgg
+        m = UNetVgg(out_classes=4, **kw)
+    else:
+        from models.unetplusplus import Nested_UNet
+        m = Nested_UNet(in_ch=1, out_ch=4)
+    return condition_(RM.hash_init_(m)).train()
 
 
 def condition_(m):
@@ -30,7 +61,7 @@ def condition_(m):
 
 
 def batch(tag=TAGS[0]):
-    return RM.synthetic_batch(2, 64, 4, in_ch=3, tag=tag)
+    return RM.synthetic_batch(2, 64, 4, in_ch=CASES[tag][2], tag=tag)
 
 
 def relu_margin(model, x):

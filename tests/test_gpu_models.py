@@ -213,15 +213,54 @@ def test_unetvgg384_fp32_mask(golden):
             assert abs(float(p.grad.double().norm()) - gn) / gn < 5e-3, k
 
 
-def test_bench_shape_properties():
-    """BASELINE shape (batch 32, 384x384, bf16): size-independent properties instead of an oracle run."""
+@pytest.mark.parametrize("tag", ["wellcond:8", "wellcond-convtrans:5", "wellcond-unetpp:8"])
+def test_bf16_meets_2e2_on_well_conditioned_cases(tag):
+    """The bf16 path against the north-star bound (rel <= 2e-2) where it can hold: on the well-conditioned cases the logits and
+    the loss of the HIP bf16 path are within 2e-2 of the fp32 reference (measured 3e-3 .. 7e-3 and <= 2e-3).  Parameter gradients
+    are not: the same network under torch's bf16 autocast on the CPU (the same rounding points) is 2e-2 .. 2e-1 away from the fp32
+    gradients on these cases, so no bf16 implementation meets 2e-2 there; the HIP gradients must be no further away than that
+    autocast run, tensor by tensor and in the median (measured: HIP median 2.3e-2 .. 4.6e-2, autocast 2.5e-2 .. 6.9e-2)."""
     from loss.dice import dice_loss_sq
     from loss.focal import focal_loss_with_logits
-    from models.unetvgg import UNetVgg
-    from oracle.ref_models import hash_init_, synthetic_batch
-    model = hash_init_(UNetVgg(out_classes=4)).cuda().train().set_compute_dtype(torch.bfloat16)
-    x, t = synthetic_batch(8, 384, 4, tag="bench")
-    x, t = x.cuda(), t.cuda()
+    from oracle import ref_losses as RL
+    from oracle import wellcond as WC
+    x, t = WC.batch(tag)
+    ref = WC.oracle_model(tag)
+    lr = ref(x)
+    loss_r = RL.dice_loss_sq(lr, t) + RL.focal_loss_with_logits(lr, t)
+    loss_r.backward()
+    auto = WC.oracle_model(tag)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        la = auto(x)
+    (RL.dice_loss_sq(la.float(), t) + RL.focal_loss_with_logits(la.float(), t)).backward()
+    net = WC.hip_model(tag).cuda().set_compute_dtype(torch.bfloat16)
+    lg = net(x.cuda())
+    loss = dice_loss_sq(lg, t.cuda()) + focal_loss_with_logits(lg, t.cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    e_logits = rel_l2(lg.detach(), lr.detach())
+    e_loss = abs(float(loss) - float(loss_r)) / abs(float(loss_r))
+    assert e_logits <= 2e-2 and e_loss <= 2e-2, (e_logits, e_loss)
+    eh, ea = [], []
+    for (k, p), (_, q), (_, qa) in zip(net.named_parameters(), ref.named_parameters(), auto.named_parameters()):
+        scale = float(q.grad.norm())
+        if scale < 1e-6:
+            continue
+        e = float((p.grad.double().cpu() - q.grad.double()).norm()) / scale
+        a = float((qa.grad.double() - q.grad.double()).norm()) / scale
+        assert e <= 1.3 * a + 2e-2, (k, e, a)
+        eh.append(e)
+        ea.append(a)
+    med = lambda v: sorted(v)[len(v) // 2]
+    print(f"{tag}: bf16 logits rel-L2 {e_logits:.2e}, loss {e_loss:.2e}; gradient rel-L2 median {med(eh):.2e} worst {max(eh):.2e} "
+          f"(torch bf16 autocast oracle: median {med(ea):.2e} worst {max(ea):.2e})")
+    assert med(eh) <= 1.1 * med(ea) + 5e-3 and max(eh) <= 1.2 * max(ea) + 2e-2
+
+
+def _bench_shape_properties(model, x, t, loss_fn):
+    """Two training steps from the same state give identical bits (logits and every gradient: fixed-order reductions everywhere),
+    everything is finite, and in eval mode an image's logits do not depend on the rest of the batch."""
+    heads = lambda out: list(out) if isinstance(out, (list, tuple)) else [out]
     outs = []
     for _ in range(2):
         model.zero_grad()
@@ -229,20 +268,45 @@ def test_bench_shape_properties():
             if isinstance(m, torch.nn.BatchNorm2d):
                 m.reset_running_stats()
         logits = model(x)
-        loss = dice_loss_sq(logits, t) + focal_loss_with_logits(logits, t)
+        loss = loss_fn(logits, t)
         loss.backward()
-        outs.append((logits.detach().clone(), [p.grad.clone() for p in model.parameters()]))
-    # deterministic: two runs give identical bits (fixed-order reductions everywhere)
-    assert torch.equal(outs[0][0], outs[1][0])
+        outs.append(([h.detach().clone() for h in heads(logits)], [p.grad.clone() for p in model.parameters()], float(loss)))
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b) and torch.isfinite(a).all()
     for a, b in zip(outs[0][1], outs[1][1]):
-        assert torch.equal(a, b)
-    assert torch.isfinite(outs[0][0]).all()
-    # batch independence of everything but BatchNorm statistics: in eval mode image i's logits do not depend on the others
+        assert torch.equal(a, b) and torch.isfinite(a).all()
+    assert outs[0][2] == outs[1][2] and np.isfinite(outs[0][2])
     model.eval()
     with torch.no_grad():
-        full = model(x)
-        part = model(x[2:4])
-    assert torch.equal(full[2:4], part)
+        full = heads(model(x))
+        part = heads(model(x[2:4]))
+    for f, p in zip(full, part):
+        assert torch.equal(f[2:4], p)
+
+
+def test_bench_shape_properties():
+    """BASELINE configs[1] at its full size (UNet-VGG, batch 32, 384x384, bf16): size-independent properties instead of an
+    oracle run."""
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetvgg import UNetVgg
+    from oracle.ref_models import hash_init_, synthetic_batch
+    model = hash_init_(UNetVgg(out_classes=4)).cuda().train().set_compute_dtype(torch.bfloat16)
+    x, t = synthetic_batch(32, 384, 4, tag="bench")
+    _bench_shape_properties(model, x.cuda(), t.cuda(), lambda lg, tt: dice_loss_sq(lg, tt) + focal_loss_with_logits(lg, tt))
+
+
+def test_bench_shape_properties_unetpp_deep_supervision():
+    """BASELINE configs[3] at its full size (UNet++ with four supervised heads, batch 16, 384x384, bf16, summed Dice + focal):
+    the same size-independent properties, on every head."""
+    from loss.dice import dice_loss_sq
+    from loss.focal import focal_loss_with_logits
+    from models.unetplusplus import Nested_UNet, deep_supervision_loss
+    from oracle.ref_models import hash_init_, synthetic_batch
+    model = hash_init_(Nested_UNet(in_ch=1, out_ch=4, deep_supervision=True)).cuda().train().set_compute_dtype(torch.bfloat16)
+    x, t = synthetic_batch(16, 384, 4, in_ch=1, tag="bench-unetpp")
+    _bench_shape_properties(model, x.cuda(), t.cuda(),
+                            lambda lg, tt: deep_supervision_loss(lg, tt, [dice_loss_sq, focal_loss_with_logits]))
 
 
 BLOCKS = [
@@ -464,50 +528,69 @@ def test_nestedunet_deep_supervision_bf16():
         assert rel_l2(p.grad, q.grad) < 1e-1, k
 
 
-@pytest.mark.parametrize("tag", ["wellcond:8", "wellcond:7"])
+@pytest.mark.parametrize("tag", ["wellcond:8", "wellcond:7", "wellcond-convtrans:5", "wellcond-unetpp:8"])
 def test_fp32_gradients_meet_1e4_on_well_conditioned_cases(tag):
-    """End-to-end fp32 gradient parity at the north-star bound.  On the well-conditioned cases (oracle/wellcond.py: no
-    pre-ReLU value within rounding of its threshold, so no ReLU mask depends on the rounding) every parameter gradient of the
-    HIP path must be within 1e-4 (relative L2) of the REFERENCE's fp32 gradient: against the reference-generated fixture
-    (norm, 4096 strided samples and four +-1 hash projections per tensor: tests/golden/wellcond.npz) and, tensor for tensor,
-    against the oracle run here (pinned bit for bit to the reference on these cases)."""
+    """End-to-end fp32 gradient parity at the north-star bound, for UNetVgg (bilinear decoder, two batches), UNetVgg with the
+    transposed-convolution decoder (models/unetvgg.py:31-32) and Nested_UNet (models/unetplusplus.py:27-82).  On the
+    well-conditioned cases (oracle/wellcond.py: no pre-ReLU value within rounding of its threshold, so no ReLU mask depends on
+    the rounding) every parameter gradient of the HIP path must be within 1e-4 (relative L2) of the REFERENCE's fp32 gradient:
+    against the reference-generated fixture (norm, 4096 strided samples and four +-1 hash projections per tensor:
+    tests/golden/wellcond.npz) and, tensor for tensor, against the oracle run here (pinned bit for bit to the reference on these
+    cases).  Where the reference's own fp32 gradient of a tensor is more than 3e-5 from exact arithmetic (two cancelling sums of
+    UNet++), two correct fp32 implementations can be further than 1e-4 apart: there the HIP gradient must be within 1e-4 of the
+    fp64 oracle, and the comparison with the reference's fp32 value gets that tensor's own fp32 error added to the bound."""
     import os
     from loss.dice import dice_loss_sq
     from loss.focal import focal_loss_with_logits
-    from models.unetvgg import UNetVgg
     from oracle import ref_losses as RL
     from oracle import ref_models as RM
     from oracle import wellcond as WC
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "wellcond.npz"))
     x, t = WC.batch(tag)
-    net = WC.condition_(RM.hash_init_(UNetVgg(out_classes=4))).cuda().train().set_compute_dtype(torch.float32)
+    net = WC.hip_model(tag).cuda().set_compute_dtype(torch.float32)
     lg = net(x.cuda())
     loss = dice_loss_sq(lg, t.cuda()) + focal_loss_with_logits(lg, t.cuda())
     loss.backward()
     torch.cuda.synchronize()
     report(f"{tag}/logits", lg.detach().cpu(), torch.from_numpy(g[f"{tag}/logits"]), rtol=1e-4, atol=1e-4)
     assert abs(float(loss) - float(g[f"{tag}/loss"])) <= 1e-4 * abs(float(g[f"{tag}/loss"]))
-    ref = WC.condition_(RM.hash_init_(RM.RefUNetVgg(out_classes=4))).train()
+    ref = WC.oracle_model(tag)
     lr = ref(x)
     (RL.dice_loss_sq(lr, t) + RL.focal_loss_with_logits(lr, t)).backward()
-    worst = 0.0
-    for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+    ref64 = WC.oracle_model(tag).double()
+    l64 = ref64(x.double())
+    (RL.dice_loss_sq(l64, t) + RL.focal_loss_with_logits(l64, t)).backward()
+    worst = worst64 = 0.0
+    loose = []
+    for (k, p), (_, q), (_, q64) in zip(net.named_parameters(), ref.named_parameters(), ref64.named_parameters()):
         got = p.grad.detach().double().flatten().cpu()
         norm = float(g[f"{tag}/grad/{k}/norm"])
         if norm < 1e-6:       # analytically zero (a bias in front of a batch-statistics norm): rounding noise in the reference
             assert float(got.norm()) < 1e-5, k
             continue
-        assert abs(float(got.norm()) - norm) <= 1e-4 * norm, k
+        exact = q64.grad.flatten()
+        ref_own = float((q.grad.double().flatten() - exact).norm()) / norm      # the reference's fp32 error on this tensor
+        err64 = float((got - exact).norm()) / norm
+        tol = 1e-4
+        if ref_own > 3e-5:
+            assert err64 <= 1e-4, f"{k}: rel-L2 {err64:.3e} against the fp64 oracle (the reference's fp32 gradient is {ref_own:.3e} from it)"
+            tol = 1e-4 + ref_own
+            loose.append((k, ref_own, err64))
+        assert abs(float(got.norm()) - norm) <= tol * norm, k
         sub = torch.from_numpy(g[f"{tag}/grad/{k}/sub"]).double()
         stride = max(1, got.numel() // 4096)
         share = (sub.numel() / got.numel()) ** 0.5                     # the samples' share of the tensor's norm
-        assert float((got[::stride][:4096] - sub).norm()) <= 1e-4 * norm * max(share, 1e-2) * 4 + 1e-12, k
+        assert float((got[::stride][:4096] - sub).norm()) <= tol * norm * max(share, 1e-2) * 4 + 1e-12, k
         for i, want in enumerate(g[f"{tag}/grad/{k}/proj"]):
             sign = RM.hash_uniform(f"proj{i}:{k}", (got.numel(),), -1, 1).sign().double()
-            assert abs(float(got @ sign) - float(want)) <= 4e-4 * norm, (k, i)
+            assert abs(float(got @ sign) - float(want)) <= 4 * tol * norm, (k, i)
         err = float((got - q.grad.double().flatten()).norm()) / norm
-        worst = max(worst, err)
-        assert err <= 1e-4, f"{k}: rel-L2 {err:.3e} against the reference's fp32 gradient"
+        worst, worst64 = max(worst, err), max(worst64, err64)
+        assert err <= tol, f"{k}: rel-L2 {err:.3e} against the reference's fp32 gradient"
+    if loose:
+        print(f"{tag}: tensors judged against the fp64 oracle (reference fp32 error, HIP error): " +
+              ", ".join(f"{k} {a:.1e}/{b:.1e}" for k, a, b in loose))
+    print(f"{tag}: worst gradient rel-L2 against the fp64 oracle {worst64:.2e}")
     print(f"{tag}: worst gradient rel-L2 against the reference's fp32 gradients {worst:.2e} "
           f"(reference fp32 vs fp64: {float(g[tag + '/reference_fp32_vs_fp64_worst_grad_rel_l2']):.2e}; smallest relative "
           f"pre-ReLU margin {float(g[tag + '/min_relu_margin']):.1e})")

@@ -352,27 +352,31 @@ def test_nestedunet_deep_supervision_host_path_equals_oracle():
 
 def test_oracle_reproduces_the_well_conditioned_fixture():
     """tests/golden/wellcond.npz comes from the reference import (oracle/make_golden_wellcond.py); the oracle must give the
-    same logits, loss and gradient summaries bit for bit, and the pin file must say so."""
+    same logits, loss and gradient summaries bit for bit on every case (UNetVgg with either decoder, Nested_UNet), and the pin
+    file must say so."""
     import json
     import os
     import numpy as np
     import torch
     from oracle import ref_losses as RL
-    from oracle import ref_models as RM
     from oracle import wellcond as WC
+    torch.set_num_threads(8)               # the fixture was made with 8 threads (the reduction order of the CPU kernels)
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     g = np.load(os.path.join(root, "wellcond.npz"))
     pins = json.load(open(os.path.join(root, "oracle_pin.json")))["checks"]
-    tag = WC.TAGS[0]
-    assert pins[f"model/{tag}"] is True and pins[f"model/{WC.TAGS[1]}"] is True
-    x, t = WC.batch(tag)
-    m = WC.condition_(RM.hash_init_(RM.RefUNetVgg(out_classes=4))).train()
-    lg = m(x)
-    loss = RL.dice_loss_sq(lg, t) + RL.focal_loss_with_logits(lg, t)
-    loss.backward()
-    assert np.array_equal(lg.detach().numpy(), g[f"{tag}/logits"]) and float(loss) == float(g[f"{tag}/loss"])
-    for k, p in m.named_parameters():
-        flat = p.grad.flatten()
-        stride = max(1, flat.numel() // 4096)
-        assert np.array_equal(flat[::stride][:4096].numpy(), g[f"{tag}/grad/{k}/sub"]), k
-    assert float(g[f"{tag}/min_relu_margin"]) > 1e-6 and float(g[f"{tag}/reference_fp32_vs_fp64_worst_grad_rel_l2"]) < 2e-5
+    assert set(WC.TAGS) <= set(WC.CASES) and len(WC.CASES) == 4
+    for tag in WC.CASES:
+        assert pins[f"model/{tag}"] is True, tag
+        x, t = WC.batch(tag)
+        m = WC.oracle_model(tag)
+        lg = m(x)
+        loss = RL.dice_loss_sq(lg, t) + RL.focal_loss_with_logits(lg, t)
+        loss.backward()
+        assert np.array_equal(lg.detach().numpy(), g[f"{tag}/logits"]) and float(loss) == float(g[f"{tag}/loss"]), tag
+        for k, p in m.named_parameters():
+            flat = p.grad.flatten()
+            stride = max(1, flat.numel() // 4096)
+            assert np.array_equal(flat[::stride][:4096].numpy(), g[f"{tag}/grad/{k}/sub"]), (tag, k)
+        assert float(g[f"{tag}/min_relu_margin"]) > 5e-7, tag
+        # the reference's own fp32 gradients against exact arithmetic: 5e-6..8e-6 for UNetVgg, 9e-5 for UNet++ (recorded, not hidden)
+        assert float(g[f"{tag}/reference_fp32_vs_fp64_worst_grad_rel_l2"]) < (1e-4 if "unetpp" in tag else 2e-5), tag
