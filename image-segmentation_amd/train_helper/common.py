@@ -5,7 +5,13 @@
 Differences, on purpose: figure export after the test pass (matplotlib) is replaced by the returned metrics
 (`model.segk_metrics`); the default network is `UNetVgg()`.  The pytorch-lightning branch (`is_naive_train=False`)
 runs on the installed pytorch_lightning, or on the minimal stand-in of segk_compat.lightning when that is absent.
+
+Two environment knobs exist so that the reference's entry scripts, which hard-code 2000 epochs and the authors' home
+directories (/root/reference/train_midlslice.py:16-17,24), can be run unedited as a check: `SEGK_MAX_EPOCHS=n` caps
+`num_epochs`, `SEGK_PATH_REMAP=old_prefix=new_prefix` re-roots `out_path`.
 """
+import os
+
 import torch
 from torch.utils.data import DataLoader
 
@@ -18,6 +24,12 @@ def train_general(dataset, out_path, expt_name="", val_set_perc=0.15, test_set_p
                   num_epochs=1, is_naive_train=False, mode=None, val_set=None, test_set=None, valid_after=4,
                   net_model=None, batch_size=3, test_batch_size=7, loss_criterion=None, val_acc_func=None,
                   sgm_train=True, lr=1e-4, use_saved=False):
+    if os.environ.get("SEGK_MAX_EPOCHS"):
+        num_epochs = min(num_epochs, int(os.environ["SEGK_MAX_EPOCHS"]))
+    if os.environ.get("SEGK_PATH_REMAP"):
+        old, new = os.environ["SEGK_PATH_REMAP"].split("=", 1)
+        if str(out_path).startswith(old):
+            out_path = new + str(out_path)[len(old):]
     if mode is None:
         val_size = int(val_set_perc * len(dataset))
         test_size = int(test_set_perc * len(dataset))

@@ -161,3 +161,38 @@ def test_pl_test_module_path_matches_the_reference():
     from pl_utils.pl_test import test_model
     from pl_utils.pl_train import test_model as same
     assert test_model is same and test_model(None, "/nonexistent", None) is None
+
+
+def test_reference_callers_pin_is_present_and_green():
+    """oracle/run_reference_callers.py executed the reference's OWN pl_utils/pl_train.py + pl_utils/pl_mod.py and train_midlslice.py
+    (unedited, from the reference tree) on this build's modules in the build container; its record must say that both ran."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(root, "tests", "golden", "callers_pin.json")))
+    assert doc["all_ran"] is True and set(doc["legs"]) == {"pl_train.py + pl_mod.py", "train_midlslice.py"}
+    pl_leg, mid = doc["legs"]["pl_train.py + pl_mod.py"], doc["legs"]["train_midlslice.py"]
+    assert pl_leg["ran"] and {"loss", "val_loss", "val_acc"} <= set(pl_leg["metrics"]) and any(f.endswith(".ckpt") for f in pl_leg["files_written"])
+    assert mid["ran"] and mid["executed_as"].startswith("__main__") and mid["train_general_called_with"]["net_model"] == "DetectMid"
+    assert mid["train_general_called_with"]["num_epochs"] == 2000 and mid["files_written"] == ["checkpoint_epoch1_train_midlsl.pth.tar"]
+    pins = json.load(open(os.path.join(root, "tests", "golden", "oracle_pin.json")))["checks"]
+    assert pins["callers/train_midlslice.py"] is True and pins["callers/pl_train.py + pl_mod.py"] is True
+
+
+def test_train_general_environment_knobs(tmp_path, monkeypatch):
+    """SEGK_MAX_EPOCHS caps the epoch count and SEGK_PATH_REMAP re-roots the output directory (the knobs that let the reference's
+    entry scripts, with their 2000 epochs and hard-coded home directories, run unedited)."""
+    import torch
+    from data_read.read_3dinput import Meniscus3DMidSlice
+    from data_read.synthetic import SyntheticSlices
+    from models.unetvgg import UNetSimple
+    from train_helper.common import train_general
+    monkeypatch.setenv("SEGK_MAX_EPOCHS", "1")
+    monkeypatch.setenv("SEGK_PATH_REMAP", f"/nonexistent/home={tmp_path}")
+    torch.manual_seed(0)
+    net = train_general(SyntheticSlices(num_img=8, side=32, n_classes=3, in_channels=1), "/nonexistent/home/run", num_epochs=50,
+                        is_naive_train=True, net_model=UNetSimple(in_classes=1, out_classes=3, channelscale=8), batch_size=4,
+                        val_set_perc=0.25, test_set_perc=0.0, device="cpu")
+    assert len(net.segk_metrics["train_loss"]) == 1 and os.path.isdir(tmp_path / "run")
+    monkeypatch.setenv("SEGK_SYNTH_3D", "5,8,32")
+    d = Meniscus3DMidSlice("/anywhere", num_img=None, in_channels=1)
+    assert len(d) == 5 and tuple(d[0][0].shape) == (1, 8, 32, 32)
