@@ -147,6 +147,19 @@ def cpu_baseline_detectmid(depth, side):
             "sample": f"oracle RefDetectMid fp32, batch 2 x 1x{depth}x{side}x{side}, fwd+loss+bwd, second of 2 steps"}
 
 
+def csrc_hash():
+    """sha256 over the kernel sources (the stamp scratch/hbm_traffic.py puts on a traffic measurement)."""
+    import hashlib
+    d = os.path.join(ROOT, "image-segmentation_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks of this script as a
     CHILD process (this process has made no GPU call and makes none), relay its output -- rank 0's JSON line is the
@@ -187,6 +200,8 @@ def main():
     ap.add_argument("--no-wgrad-stream", action="store_true",
                     help="keep the weight gradients on the main stream (default: on a second HIP stream next to the data gradients, "
                          "except on the steps whose launches are event-timed and with more than one rank)")
+    ap.add_argument("--bucket-mb", type=float, default=25.0,
+                    help="size of the flat gradient buckets that are all-reduced one by one while the backward pass is still running")
     ap.add_argument("--launch-table", default=None,
                     help="also write the event-timed duration of every convolution launch of a step (mean over the event-timed steps, "
                          "in launch order, with its shape) to this JSON file")
@@ -197,10 +212,22 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args.gpus))          # before anything touches the GPU: the ranks are child processes
+    # Rank 0 prints exactly one line on stdout.  Libraries write there too (RCCL prints a version banner when its first
+    # communicator is made), so file descriptor 1 is pointed at stderr for the run and the line goes to a copy of the real one.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
                  f"(or run `python bench.py --gpus {args.gpus}` directly, which starts the ranks itself)")
+    if args.batch is None:
+        # UNet-VGG 32 and UNet++ 16 as BASELINE.json quotes them; the 3-D classifier at the reference's own 12 (train_midlslice.py:24)
+        args.batch = {"unetpp": 16, "unetsimple": 16, "spidernet": 8, "detectmid": 12}.get(args.model, 32)
+    if args.strong:
+        if args.batch % world:
+            sys.exit(f"bench.py --strong: global batch {args.batch} does not divide over {world} ranks")
+        args.batch //= world
     if args.dry_run:
         import torch.distributed as dist
         seen = 1
@@ -211,15 +238,9 @@ def main():
             seen = int(one.item())
             dist.destroy_process_group()
         if int(os.environ.get("RANK", "0")) == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": seen, "steps": args.steps, "warmup": args.warmup}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": seen, "steps": args.steps, "warmup": args.warmup, "scaling": "strong" if args.strong else "weak",
+                              "batch_per_gpu": args.batch, "global_batch": seen * args.batch, "bucket_mb": args.bucket_mb}), file=real_stdout, flush=True)
         return
-    if args.batch is None:
-        # UNet-VGG 32 and UNet++ 16 as BASELINE.json quotes them; the 3-D classifier at the reference's own 12 (train_midlslice.py:24)
-        args.batch = {"unetpp": 16, "unetsimple": 16, "spidernet": 8, "detectmid": 12}.get(args.model, 32)
-    if args.strong:
-        if args.batch % world:
-            sys.exit(f"bench.py --strong: global batch {args.batch} does not divide over {world} ranks")
-        args.batch //= world
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     local = local % max(torch.cuda.device_count(), 1)     # rehearsals may put several ranks on one card (gloo only)
@@ -232,6 +253,19 @@ def main():
             dist.init_process_group(args.backend)
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
+    forced = world == 1 and os.environ.get("SEGK_FORCE_COLLECTIVES") == "1"
+    if forced:
+        # a one-rank RCCL group whose bucket all-reduces are really issued (identity): what the collective machinery costs
+        # per step by itself -- events, the communication stream, one RCCL launch per bucket -- without any inter-GPU transfer
+        import socket
+        import torch.distributed as dist
+        if "MASTER_PORT" not in os.environ:
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, rank=0, world_size=1, **({"device_id": device} if args.backend == "nccl" else {}))
 
     from loss.dice import dice_loss_sq
     from loss.focal import focal_loss_with_logits
@@ -269,7 +303,7 @@ def main():
         gflop = GFLOP_PER_SLICE if args.model == "unetvgg" else 539.05
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = model.to(device).train().set_compute_dtype(dtype)
-    flat = FlatModel(model)                    # flat params/grads; bucketed all-reduce when world > 1
+    flat = FlatModel(model, bucket_mb=args.bucket_mb)      # flat params/grads; bucketed all-reduce when world > 1
     opt = Adam(flat, lr=1e-4)
     if args.model == "detectmid":
         g = torch.Generator().manual_seed(20 + rank)
@@ -307,6 +341,8 @@ def main():
     # ~2 % of the step; they are recorded on every 4th timed step only, inside the timed region.
     timer = None if args.no_roofline else []
     timed_steps = 0
+    if flat.buckets.active:
+        flat.buckets.exposed = []              # events around the compute stream's wait for the collectives, every step
     t0 = time.perf_counter()
     for i in range(args.steps):
         sample = timer is not None and i % 4 == 0
@@ -323,6 +359,25 @@ def main():
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
     final_loss = float(loss.detach())
+    exposed_ms = None
+    if flat.buckets.exposed:
+        exposed_ms = sum(a.elapsed_time(b) for a, b in flat.buckets.exposed) / len(flat.buckets.exposed)
+    flat.buckets.exposed = None
+    overhead_ms = None
+    if forced:                                   # the same steps with the collectives switched off: the difference is their fixed cost
+        k3 = max(5, min(10, args.steps))
+        times = {}
+        for active in (True, False, True, False):
+            flat.buckets.active = active
+            step()
+            barrier()
+            t2 = time.perf_counter()
+            for _ in range(k3):
+                step()
+            barrier()
+            times.setdefault(active, []).append((time.perf_counter() - t2) / k3 * 1e3)
+        flat.buckets.active = True
+        overhead_ms = min(times[True]) - min(times[False])
     # second number: forward + loss + backward (+ all-reduce) only, no optimizer step
     k2 = max(3, min(10, args.steps))
     engine._WGRAD_STREAM = overlap
@@ -374,8 +429,16 @@ def main():
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "random_init_weights": True,
                        "final_loss": round(final_loss, 5), "h2d_ms_per_batch": round(h2d_ms, 3),
                        "slices_per_s_without_optimizer_step": round(world * args.batch * k2 / no_opt, 2),
-                       "collective": (f"{torch.distributed.get_backend()} all-reduce, {torch.distributed.get_world_size()} ranks, "
-                                      f"{len(flat.buckets.ranges)} buckets") if world > 1 else None,
+                       "collective": ({"backend": torch.distributed.get_backend(), "ranks": torch.distributed.get_world_size(),
+                                       "op": "all-reduce (average) of the flat fp32 gradient, one call per bucket on a communication stream, "
+                                             "launched when the backward pass has written the bucket's last gradient",
+                                       "bucket_mb_requested": args.bucket_mb,
+                                       "bucket_bytes": [4 * (hi - lo) for lo, hi in flat.buckets.ranges],
+                                       "exposed_wait_ms_per_step": None if exposed_ms is None else round(exposed_ms, 3),
+                                       "weight_gradients_on_side_stream": bool(engine._WGRAD_STREAM and (world == 1 or engine._WGRAD_STREAM_DP)),
+                                       "one_rank_forced": forced,
+                                       "one_rank_overhead_ms_per_step": None if overhead_ms is None else round(overhead_ms, 3)}
+                                      if flat.buckets.active else None),
                        "value_if_h2d_not_overlapped": round(world * args.batch * args.steps / (elapsed + args.steps * h2d_ms / 1e3), 2)},
         }
         if timer:
@@ -420,16 +483,22 @@ def main():
                 gflop = sum(fl for _, _, _, fl, _, _ in timer) / timed_steps / args.batch / 1e9
             achieved = gflop * args.batch / conv_ms        # GFLOP / ms = TFLOP/s
             peak = MFMA_PEAK_TFLOPS[args.dtype]
-            # HBM bytes of the same launches (one step) from the committed PMC passes of this workload; null for other workloads
-            traffic = None
-            tfile = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+            # HBM bytes of the same launches (one step) from the committed PMC passes of this workload (counters cannot be read
+            # from inside this process): reported only while the kernel sources are the ones the passes were taken on
+            traffic, traffic_note = None, None
+            tfile = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
             if args.model == "unetvgg" and args.dtype == "bf16" and args.batch == 32 and args.side == 384 and os.path.exists(tfile):  # noqa: E501
                 with open(tfile) as f:
-                    traffic = json.load(f).get("conv_mfma_kernels_hbm_bytes_per_step")
+                    tdoc = json.load(f)
+                if tdoc.get("csrc_sha256") == csrc_hash():
+                    traffic = tdoc.get("conv_mfma_kernels_hbm_bytes_per_step")
+                    traffic_note = (f"HBM bytes per step of these launches (rocprofv3 PMC, profiles/r03_hbm_traffic.json, taken on these kernel "
+                                    f"sources); algorithmic minimum {ALGO_CONV_GB_PER_STEP} GB")
+                else:
+                    traffic_note = ("profiles/r03_hbm_traffic.json was measured on other kernel sources (csrc hash differs): not reported; "
+                                    "re-run scratch/profile_round.sh")
             out["roofline"] = {"bound": "mfma", "achieved": round(achieved, 1), "peak": peak, "unit": "TFLOP/s",
-                               "frac": round(achieved / peak, 4), "traffic": traffic,
-                               "traffic_note": ("HBM bytes per step of these launches (rocprofv3 PMC, profiles/r02_hbm_traffic.json); "
-                                                f"algorithmic minimum {ALGO_CONV_GB_PER_STEP} GB") if traffic else None,
+                               "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_note": traffic_note,
                                "kernel": "conv_fwd_kernel + conv_wgrad_kernel (all MFMA convolution launches of a step)",
                                "launches_per_step": len(timer) // timed_steps, "conv_ms_per_step": round(conv_ms, 3),
                                "conv_ms_per_step_raw_events": round(raw_ms, 3), "event_marker_pair_us": round(1e3 * marker_ms, 2),
@@ -456,8 +525,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline_detectmid(args.depth, args.side) if args.model == "detectmid" else cpu_baseline(n_classes)
             if args.model not in ("unetvgg", "detectmid"):
                 out["cpu_baseline"]["sample"] += " (the headline UNet-VGG workload, not this model)"
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=real_stdout, flush=True)
+    if world > 1 or forced:
         torch.distributed.destroy_process_group()
 
 

@@ -25,15 +25,16 @@ _NO_CONV_STATS = bool(os.environ.get("SEGK_NO_CONV_STATS"))   # experiments: sep
 # kernels can run side by side and fill each other's tails and the under-occupied small layers (gradients are bitwise
 # the same either way).  On by default with one rank; SEGK_WGRAD_STREAM=0 turns it off.
 _WGRAD_STREAM = os.environ.get("SEGK_WGRAD_STREAM", "1") == "1"
-# With more than one rank the side stream stays off unless asked for (SEGK_WGRAD_STREAM_DP=1): the bucket all-reduces then wait
-# for both streams (segk/flat.py), but three concurrent streams next to RCCL's own have only been run with a one-rank group.
-_WGRAD_STREAM_DP = os.environ.get("SEGK_WGRAD_STREAM_DP", "0") == "1"
+# With more than one rank the side stream is used as well (SEGK_WGRAD_STREAM_DP=0 keeps the weight gradients on the main stream
+# there): a bucket's all-reduce waits for BOTH streams (segk/flat.py), and a one-rank RCCL group with forced collectives runs
+# exactly this three-stream schedule with bitwise unchanged gradients (tests/rccl_worker.py).  One setting for every rank count
+# also keeps the N = 1 point of a scaling curve like for like with the others.
+_WGRAD_STREAM_DP = os.environ.get("SEGK_WGRAD_STREAM_DP", "1") == "1"
 _side_streams = {}
 
 
 def _data_parallel():
-    """More than one rank: the side stream stays off by default.  Bucket all-reduces are then launched from inside it, and that
-    combination cannot be exercised where only one GPU is at hand (RCCL refuses two ranks on one device)."""
+    """More than one rank (bucket all-reduces are then launched from inside the backward pass)."""
     return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
 
 

@@ -3,9 +3,22 @@
 Both counters are in KiB; on gfx950 FETCH_SIZE tallies 128-byte requests as 64 bytes, so reads are doubled."""
 import collections
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
+
+
+def csrc_hash():
+    """sha256 over the kernel sources the measurement belongs to (bench.py reports the traffic only while it matches)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "image-segmentation_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
 
 
 def per_kernel(path):
@@ -33,6 +46,7 @@ for name in sorted(fetch, key=lambda k: -sum(fetch[k]) * 2 - sum(write.get(k, []
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 2 --warmup 1`; "
                      "KiB counters; FETCH_SIZE doubled (gfx950 tallies 128-B requests at 64 B)",
            "steps_profiled": steps,
+           "csrc_sha256": csrc_hash(),
            "conv_mfma_kernels_hbm_bytes_per_step": int(conv / steps),
            "all_kernels_hbm_bytes_per_step": int(total / steps),
            "kernels": kernels}, sys.stdout, indent=1)

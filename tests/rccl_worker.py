@@ -1,7 +1,9 @@
 """Worker of tests/test_zz_gpu_data_parallel.py::test_rccl_branch_single_rank: ONE rank with the `nccl` (= RCCL) backend on
 the one GPU, collectives forced on (SEGK_FORCE_COLLECTIVES=1), so that the RCCL branch of the bucketed all-reduce -- event
 on the compute stream, wait on the communication stream, `all_reduce` on device memory, scaling, event back -- executes
-for real.  With one rank the reduction is the identity: gradients and the Adam update must equal those of a plain run."""
+for real, with the weight gradients on their side stream as in every other run (three streams: compute, weight gradients,
+communication).  With one rank the reduction (an average over the ranks) is the identity: gradients and the Adam update must
+equal those of a plain run bit for bit."""
 import os
 import sys
 
@@ -45,6 +47,9 @@ def main():
         step(model)
     torch.cuda.synchronize()
     dist.all_reduce = real
+    from segk import engine
+    # the weight gradients ran on the side stream: the bucket all-reduces waited for two producer streams next to their own
+    assert engine._WGRAD_STREAM and engine.side_stream(torch.device("cuda", 0), create=False) is not None
     n = len(flat.buckets.ranges)
     assert n >= 3 and len(seen) == 2 * n and all(cuda and on_comm for cuda, on_comm in seen), (n, seen[:4])
     for (k, p), (_, q) in zip(model.named_parameters(), plain.named_parameters()):

@@ -269,7 +269,16 @@ def test_bench_launcher_starts_the_ranks_itself():
                        capture_output=True, text=True, timeout=240, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 3
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["batch_per_gpu"] == 32 and line["global_batch"] == 64
+    # --strong: the batch is the global one, divided over the ranks; --bucket-mb reaches the ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--strong", "--bucket-mb", "10"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["batch_per_gpu"] == 16 and line["global_batch"] == 32 and line["bucket_mb"] == 10
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--strong", "--batch", "33"],
+                       capture_output=True, text=True, timeout=240, env=env)
+    assert r.returncode != 0 and "does not divide" in r.stderr
     env["WORLD_SIZE"] = "1"
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
                        text=True, timeout=120, env=env)
