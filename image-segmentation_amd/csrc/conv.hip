@@ -1200,11 +1200,83 @@ __global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce_kernel(const f
     }
 }
 
+// The same reduction with four consecutive input channels per lane (16-byte slab reads): for channel counts and segment
+// boundaries that are multiples of 4, i.e. every layer but the patch rows of a first convolution.
+template <int P>
+__global__ __launch_bounds__(kConvThreads) void conv_wgrad_reduce4_kernel(const float* __restrict__ slab, int splits, int64_t co_tot,
+                                                                          int taps, int cin_tot, int cout_real, int cin_real,
+                                                                          int seg0, int k0_pad, float* __restrict__ dw,
+                                                                          int accumulate, int ct_cout, int ct_k0, int ct_k1,
+                                                                          int ct_k2, int ct_k3, int64_t dw_so, int64_t dw_si, int nkd) {
+    constexpr int OPW = 64 / P;   // output vectors per wavefront
+    const int cv = cin_real / 4;
+    const int64_t total = (int64_t)cout_real * cv * taps * nkd;
+    const int lane = threadIdx.x & 63, p = lane / OPW, c = lane % OPW;
+    const int64_t waves = (int64_t)gridDim.x * (kConvThreads / 64);
+    const int64_t split_stride = co_tot * taps * cin_tot;
+    for (int64_t w = (int64_t)blockIdx.x * (kConvThreads / 64) + (threadIdx.x >> 6); w * OPW < total; w += waves) {
+        const int64_t i = w * OPW + c;
+        const bool live = i < total;
+        const int ci = live ? (int)(i % cv) * 4 : 0;
+        int64_t r = live ? i / cv : 0;
+        const int t = (int)(r % taps); r /= taps;
+        const int kdi = (int)(r % nkd);
+        const int co = (int)(r / nkd);
+        const int kc = ci < seg0 ? ci : k0_pad + (ci - seg0);
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live) {
+            const float* src = slab + (((int64_t)kdi * splits * co_tot + co) * taps + t) * cin_tot + kc;
+            int k = p;
+            // two independent chains of loads in flight per lane
+            float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (; k + P < splits; k += 2 * P) {
+                const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)k * split_stride);
+                const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)(k + P) * split_stride);
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+                s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+            }
+            if (k < splits) {
+                const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)k * split_stride);
+                s.x += a.x; s.y += a.y; s.z += a.z; s.w += a.w;
+            }
+            s.x += s2.x; s.y += s2.y; s.z += s2.z; s.w += s2.w;
+        }
+#pragma unroll
+        for (int o = OPW; o < 64; o <<= 1) {
+            s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+        }
+        if (!live || p != 0) continue;
+        const float v[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float* d = ct_cout > 0 ? dw + ((int64_t)(ci + e) * ct_cout + co) * 16 + (t == 0 ? ct_k0 : t == 1 ? ct_k1 : t == 2 ? ct_k2 : ct_k3)
+                                   : dw + co * dw_so + (ci + e) * dw_si + kdi * taps + t;
+            *d = accumulate ? *d + v[e] : v[e];
+        }
+    }
+}
+
 static void launch_wgrad_reduce(hipStream_t st, const float* slab, int splits, int64_t co_tot, int taps, int cin_tot, int cout_real,
                                 int cin_real, int seg0, int k0_pad, float* dw, int accumulate, int ct_cout = 0, int k0 = 0, int k1 = 0,
                                 int k2 = 0, int k3 = 0, int64_t dw_so = 0, int64_t dw_si = 0, int nkd = 1) {
     const int64_t total = (int64_t)cout_real * cin_real * taps * nkd;
     if (dw_so == 0) { dw_so = (int64_t)cin_real * taps; dw_si = taps; }   // contiguous OIHW
+    static const bool scalar_only = getenv("SEGK_WGRAD_REDUCE_SCALAR") != nullptr;   // experiment switch
+    if (cin_real % 4 == 0 && seg0 % 4 == 0 && k0_pad % 4 == 0 && cin_tot % 4 == 0 && !scalar_only) {
+        const int64_t vecs = total / 4;
+        if (splits >= 32) {
+            int64_t grid = (vecs * 8 + kConvThreads - 1) / kConvThreads;
+            if (grid > 16384) grid = 16384;
+            hipLaunchKernelGGL(conv_wgrad_reduce4_kernel<8>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
+                               cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si, nkd);
+        } else {
+            int64_t grid = (vecs + kConvThreads - 1) / kConvThreads;
+            if (grid > 8192) grid = 8192;
+            hipLaunchKernelGGL(conv_wgrad_reduce4_kernel<1>, dim3((unsigned)grid), dim3(kConvThreads), 0, st, slab, splits, co_tot, taps, cin_tot,
+                               cout_real, cin_real, seg0, k0_pad, dw, accumulate, ct_cout, k0, k1, k2, k3, dw_so, dw_si, nkd);
+        }
+        return;
+    }
     if (splits >= 32) {
         int64_t grid = (total * 8 + kConvThreads - 1) / kConvThreads;
         if (grid > 16384) grid = 16384;
