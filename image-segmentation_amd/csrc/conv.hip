@@ -634,6 +634,300 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel for THIN layers (bf16, 3x3, few input channels, one output-channel block):
+// 64 -> 64 and 96 -> 32 at 384^2, 128 -> 32 at 192^2 and the data gradients 32 -> 96, 32 -> 128.  These layers move
+// about as many bytes as they multiply (the machine balance), and the LDS-staged kernel above cannot keep enough bytes in
+// flight for them: its in-flight data is what fits in LDS next to the weights (~45 KB per CU, ~3 TB/s at the latency
+// under load).  Here the roles are swapped:
+//   * the WHOLE packed weight image of the layer (all taps, <= 147 KB) is copied into LDS once per workgroup and stays;
+//   * every wavefront is an independent pipeline with no barrier in its loop: it owns a strip 16 pixels wide and walks down
+//     it two output rows at a time, loading its pixel fragments STRAIGHT from global memory into registers in the matrix
+//     instruction's operand layout (lane (g, p) = 16 bytes: channels 8g..8g+7 of a 32-channel k-substep of pixel p), rows
+//     requested PD steps ahead, so the register file (512 KB per CU), not LDS, holds the bytes in flight;
+//   * the fragments of the taps kx = 0 and 2 are the centre fragment shifted by one lane within its 16-lane row (one DPP
+//     move per register), with the strip's neighbouring pixel column, loaded separately, entering at lane 0 or 15.
+// The accumulation order per output element is that of the kernel above (K-row, tap, k-substep), so the results are bit
+// for bit the same.
+// ------------------------------------------------------------------------------------------------
+struct DirectArgs {
+    const char* seg0; const char* seg1;   // input segments
+    int64_t ldb0, ldb1;                   // their pixel strides in bytes
+    int off1;                             // byte offset of K-row 1 inside a pixel of segment 0 (when there is no segment 1)
+    int N, H, W, strips_x, seg_rows, segs_y, units;
+    const char* w;                        // packed image [K-row][tap][BN][128 B]
+    int Cout; const float* bias;
+    char* y; int64_t ldy; char* y1; int64_t ldy1; int split, accumulate, accumulate1;
+    const char* mask; int64_t ld_mask; int mask_c; int relu;
+    float* stat_part; int tiles_x, tiles_y;
+    int pair_first;                       // 32-channel output groups from this one on are stored in pairs (whole cache lines)
+};
+
+constexpr int kDirectWaves = 8;
+
+// NK0 / NK1: k-substeps (32 channels each) of K-row 0 / K-row 1 (0: a single K-row); NI: 16-channel output tiles (BN = 16 NI);
+// PD: how many steps ahead the rows of a step are requested
+// STATS: the epilogue also produces the per-channel sums for the normalisation that follows (a.stat_part is set)
+// MASK: a.mask is set (a data gradient that applies its producers' ReLU backward): the mask vectors of a step are requested
+// before its matrix instructions, like the pixel rows, instead of in the epilogue
+// ABUF: 2 = the weight fragments of the next block are read while this block is multiplied; 1 = read right before use (wide
+// output blocks, whose sixteen matrix instructions per block cover most of the read by themselves and whose registers are short)
+// NCB: output-channel blocks of BN channels; the weights of all of them stay in LDS and a unit of work is (block, strip segment)
+template <int NK0, int NK1, int NI, int PD, bool STATS, bool MASK, int ABUF = 2, int NCB = 1>
+__global__ __launch_bounds__(64 * kDirectWaves, 2) void conv_direct_kernel(const DirectArgs a) {
+    constexpr int NKS = NK0 + NK1, NCH = NK1 ? 2 : 1, BN = NI * 16, RING = 4 + 2 * PD;
+    constexpr int WBYTES = NCH * 9 * NCB * BN * kRowBytes;
+    static_assert(NI % 2 == 0 && WBYTES <= 150 * 1024, "weight image must fit in LDS");
+    __shared__ __attribute__((aligned(16))) char sw[WBYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, l15 = lane & 15;
+    for (int q = tid; q < WBYTES / 16; q += 64 * kDirectWaves)
+        *reinterpret_cast<Slot*>(sw + q * 16) = *reinterpret_cast<const Slot*>(a.w + (int64_t)q * 16);
+    __syncthreads();
+
+    // per k-substep: segment base, pixel stride and byte offset of this lane's 16 bytes inside a pixel
+    const char* kbase[NKS];
+    int64_t kld[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        const bool row1 = s >= NK0;
+        const bool from1 = row1 && a.seg1 != nullptr;
+        kbase[s] = (from1 ? a.seg1 : a.seg0) + (row1 && !from1 ? a.off1 : 0) + (row1 ? s - NK0 : s) * 64 + g * 16;
+        kld[s] = from1 ? a.ldb1 : a.ldb0;
+    }
+    // A (weight) fragment addresses: row co = i*16 + l15 of the (K-row, tap) image, slot (ks*4 + g) ^ (co & 7)
+    int aoff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) aoff[ks] = l15 * kRowBytes + (((ks * 4 + g) ^ (l15 & 7)) << 4);
+
+    auto shift = [](const Slot& edge, const Slot& ctr, auto dir) -> Slot {
+        // lane p of every 16-lane row takes the centre fragment of lane p-1 (dir 0: tap kx = 0) or p+1 (dir 1: kx = 2); the lane
+        // that has no such neighbour keeps `edge`, the pixel beside the strip
+        constexpr int ctrl = decltype(dir)::value == 0 ? 0x111 : 0x101;   // row_shr:1 / row_shl:1
+        Slot r;
+        r.x = (unsigned)__builtin_amdgcn_update_dpp((int)edge.x, (int)ctr.x, ctrl, 0xf, 0xf, false);
+        r.y = (unsigned)__builtin_amdgcn_update_dpp((int)edge.y, (int)ctr.y, ctrl, 0xf, 0xf, false);
+        r.z = (unsigned)__builtin_amdgcn_update_dpp((int)edge.z, (int)ctr.z, ctrl, 0xf, 0xf, false);
+        r.w = (unsigned)__builtin_amdgcn_update_dpp((int)edge.w, (int)ctr.w, ctrl, 0xf, 0xf, false);
+        return r;
+    };
+
+    const int total_waves = gridDim.x * kDirectWaves;
+    for (int u = blockIdx.x * kDirectWaves + wave; u < a.units; u += total_waves) {
+        const int sx = u % a.strips_x;
+        const int sy = (u / a.strips_x) % a.segs_y;
+        const int ncb_n = u / (a.strips_x * a.segs_y);
+        const int n = ncb_n / NCB, cb = ncb_n % NCB;
+        const int x0 = sx * kTW, ys = sy * a.seg_rows;
+        const int rows_here = min(a.seg_rows, a.H - ys);
+        const int nsteps = rows_here >> 1;
+        // the strip's neighbouring pixel column: lanes 0-7 of a row carry the left one, lanes 8-15 the right one
+        const int ex = l15 < 8 ? x0 - 1 : x0 + kTW;
+        const bool ex_ok = ex >= 0 && ex < a.W;
+
+        Slot ctr[RING][NKS], edg[RING][NKS];
+        auto load_row = [&](auto slot_tag, int r) {
+            constexpr int sl = decltype(slot_tag)::value;
+            const int yy = ys - 1 + r;
+            if (r >= rows_here + 2) return;                       // not needed by any step of this unit
+            if ((unsigned)yy < (unsigned)a.H) {
+                const int64_t rowpix = ((int64_t)n * a.H + yy) * a.W;
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) {
+                    ctr[sl][s] = *reinterpret_cast<const Slot*>(kbase[s] + (rowpix + x0 + l15) * kld[s]);
+                    edg[sl][s] = ex_ok ? *reinterpret_cast<const Slot*>(kbase[s] + (rowpix + ex) * kld[s]) : zero_slot();
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) { ctr[sl][s] = zero_slot(); edg[sl][s] = zero_slot(); }
+            }
+        };
+        // rows of the first PD steps
+        [&]<int... R>(std::integer_sequence<int, R...>) { (load_row(std::integral_constant<int, R % RING>{}, R), ...); }(
+            std::make_integer_sequence<int, 2 * PD + 2>{});
+
+        float ssum[STATS ? NI / 2 : 1][8], ssq[STATS ? NI / 2 : 1][8];
+        if constexpr (STATS) {
+#pragma unroll
+            for (int k2 = 0; k2 < NI / 2; ++k2)
+#pragma unroll
+                for (int r = 0; r < 8; ++r) ssum[k2][r] = ssq[k2][r] = 0.f;
+        }
+
+        auto step = [&](auto q_tag, int st) {
+            constexpr int q = decltype(q_tag)::value;             // position inside the unrolled group: window slots 2q .. 2q+3
+            // request the rows of step st + PD
+            load_row(std::integral_constant<int, (2 * q + 2 * PD + 2) % RING>{}, 2 * st + 2 * PD + 2);
+            load_row(std::integral_constant<int, (2 * q + 2 * PD + 3) % RING>{}, 2 * st + 2 * PD + 3);
+            Slot mk[MASK ? 2 : 1][MASK ? NI / 2 : 1];
+            if constexpr (MASK) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int64_t pix = ((int64_t)n * a.H + ys + 2 * st + j) * a.W + x0 + l15;
+#pragma unroll
+                    for (int k2 = 0; k2 < NI / 2; ++k2) {
+                        const int co = cb * BN + 32 * k2 + 8 * g;
+                        mk[j][k2] = co < a.mask_c ? *reinterpret_cast<const Slot*>(reinterpret_cast<const bf16*>(a.mask) + pix * a.ld_mask + co)
+                                                  : make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);   // ones: keep
+                    }
+                }
+            }
+            f32x4 acc[NI][2];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) { acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            // blocks (K-row, tap, k-substep) in the accumulation order of conv_fwd_kernel; the weight fragments of block b+1 are
+            // read from LDS before the matrix instructions of block b are issued
+            constexpr int NBLK = 9 * NKS;
+            auto read_a = [&](auto b_tag, Slot (&fa)[NI]) {
+                constexpr int b = decltype(b_tag)::value;
+                constexpr int c = b < 9 * NK0 ? 0 : 1, bb = c == 0 ? b : b - 9 * NK0, nk = c == 0 ? NK0 : NK1;
+                constexpr int tap = bb / nk, ks = bb % nk;
+                const char* wt = sw + ((c * 9 + tap) * NCB + cb) * BN * kRowBytes;
+#pragma unroll
+                for (int i = 0; i < NI; ++i) fa[i] = *reinterpret_cast<const Slot*>(wt + i * 16 * kRowBytes + aoff[ks]);
+            };
+            Slot fa[ABUF][NI];
+            if constexpr (ABUF == 2) read_a(std::integral_constant<int, 0>{}, fa[0]);
+            [&]<int... B>(std::integer_sequence<int, B...>) {
+                ([&] {
+                    constexpr int b = B;
+                    constexpr int c = b < 9 * NK0 ? 0 : 1, bb = c == 0 ? b : b - 9 * NK0, nk = c == 0 ? NK0 : NK1;
+                    constexpr int tap = bb / nk, ks = bb % nk, s = c == 0 ? ks : NK0 + ks;
+                    constexpr int ky = tap / 3, kx = tap % 3;
+                    if constexpr (ABUF == 1) read_a(std::integral_constant<int, b>{}, fa[0]);
+                    else if constexpr (b + 1 < NBLK) read_a(std::integral_constant<int, b + 1>{}, fa[(b + 1) & 1]);
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int sl = (2 * q + j + ky) % RING;
+                        Slot fb;
+                        if constexpr (kx == 1) fb = ctr[sl][s];
+                        else if constexpr (kx == 0) fb = shift(edg[sl][s], ctr[sl][s], std::integral_constant<int, 0>{});
+                        else fb = shift(edg[sl][s], ctr[sl][s], std::integral_constant<int, 1>{});
+#pragma unroll
+                        for (int i = 0; i < NI; ++i) Mma<bf16>::run(fa[ABUF == 2 ? (b & 1) : 0][i], fb, acc[i][j]);
+                    }
+                    // keep the scheduler from pulling the weight reads of later blocks (and their registers) up here
+                    __builtin_amdgcn_sched_barrier(0);
+                }(), ...);
+            }(std::make_integer_sequence<int, NBLK>{});
+            // epilogue of the two rows: the conv_fwd_kernel epilogue for one pixel row per j.  The results are first packed to
+            // bf16, then stored: a lane holds 16 bytes (8 channels) of a pixel, four lanes (g) one 64-byte half of a 64-channel
+            // stretch, so one store instruction per 32-channel group writes HALF cache lines of 16 pixels.  Where two groups
+            // are neighbours in the same tensor they are stored as a pair instead: the lanes of pixels 8-15 trade their group-A
+            // vector for the group-B vector of pixels 0-7 (one rotate by 8 lanes per register), so that each of the two
+            // instructions writes whole 128-byte lines of 8 pixels.
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int yy = ys + 2 * st + j;
+                const int64_t pix0 = ((int64_t)n * a.H + yy) * a.W + x0;
+                const int64_t pix = pix0 + l15;
+                Slot outp[NI / 2];
+#pragma unroll
+                for (int k2 = 0; k2 < NI / 2; ++k2) {
+                    const int co = cb * BN + 32 * k2 + 8 * g;
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e]; v[4 + e] = acc[2 * k2 + 1][j][e]; }
+                    if (a.bias && co < a.Cout) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+                    }
+                    if constexpr (MASK) {
+                        // a bf16 is positive exactly when its 16 bits, read as a signed integer, are
+                        const unsigned mw[4] = {mk[j][k2].x, mk[j][k2].y, mk[j][k2].z, mk[j][k2].w};
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] = (short)(mw[r >> 1] >> (16 * (r & 1))) > 0 ? v[r] : 0.f;
+                    }
+                    const bool second = co >= a.split;
+                    if ((second ? a.accumulate1 : a.accumulate) && co < a.Cout) {
+                        const bf16* dst = second ? reinterpret_cast<const bf16*>(a.y1) + pix * a.ldy1 + (co - a.split)
+                                                 : reinterpret_cast<const bf16*>(a.y) + pix * a.ldy + co;
+                        float o[8];
+                        Elem<bf16>::load8(dst, o);
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) v[r] += o[r];
+                    }
+                    bf16x8 pk;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) pk[r] = (bf16)v[r];
+                    outp[k2] = __builtin_bit_cast(Slot, pk);
+                    if constexpr (STATS) {
+                        if (co < a.Cout) {
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) {
+                                const float qv = (float)pk[r];
+                                ssum[k2][r] += qv;
+                                ssq[k2][r] += qv * qv;
+                            }
+                        }
+                    }
+                }
+                auto dst_of = [&](int64_t p, int co) -> char* {
+                    return co >= a.split ? a.y1 + (p * a.ldy1 + (co - a.split)) * 2 : a.y + (p * a.ldy + co) * 2;
+                };
+#pragma unroll
+                for (int k2 = 0; k2 < NI / 2; ++k2) {
+                    const int cg0 = cb * BN + 32 * k2;                          // first channel of the group
+                    if (cg0 >= a.Cout) continue;
+                    const int rel = k2 - a.pair_first;
+                    if (rel >= 0 && (rel & 1)) continue;                        // second half of a pair: already stored
+                    if (rel >= 0 && k2 + 1 < NI / 2 && cg0 + 32 < a.Cout) {
+                        const bool hi = l15 >= 8;
+                        const Slot A = outp[k2], B = outp[k2 + 1 < NI / 2 ? k2 + 1 : k2];
+                        auto ror8 = [](unsigned x) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x128, 0xf, 0xf, false); };
+                        const Slot Ar = make_uint4(ror8(A.x), ror8(A.y), ror8(A.z), ror8(A.w));
+                        const Slot Br = make_uint4(ror8(B.x), ror8(B.y), ror8(B.z), ror8(B.w));
+                        const Slot SA = hi ? Br : A, SB = hi ? B : Ar;
+                        const int co = cg0 + 8 * g + (hi ? 32 : 0);
+                        if (co < a.Cout) {                                      // Cout need not fill its last 32-channel group
+                            *reinterpret_cast<Slot*>(dst_of(pix0 + (l15 & 7), co)) = SA;
+                            *reinterpret_cast<Slot*>(dst_of(pix0 + 8 + (l15 & 7), co)) = SB;
+                        }
+                    } else if (cg0 + 8 * g < a.Cout) {
+                        *reinterpret_cast<Slot*>(dst_of(pix, cg0 + 8 * g)) = outp[k2];
+                    }
+                }
+            }
+            // statistics rows keep the layout of conv_fwd_kernel's (one row per 8x16 tile and group of pixel rows): a row is
+            // closed after every `stat_rows` output rows
+            if constexpr (STATS) {
+                const int stat_rows = (BN == 64 || BN == 128) ? 4 : 2;   // rows per pixel-wave of the LDS-staged variant of this width
+                const int yy1 = ys + 2 * st + 1;
+                if ((yy1 + 1) % stat_rows == 0) {
+                    const int ty = yy1 / 8, wpx = (yy1 % 8) / stat_rows;
+                    const int tile = (n * a.tiles_y + ty) * a.tiles_x + sx;
+#pragma unroll
+                    for (int k2 = 0; k2 < NI / 2; ++k2) {
+                        const int co = cb * BN + 32 * k2 + 8 * g;
+                        if (co >= a.Cout) continue;
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) { ssum[k2][r] = row16_sum(ssum[k2][r]); ssq[k2][r] = row16_sum(ssq[k2][r]); }
+                        if (l15 == 0) {
+                            float* dst = a.stat_part + ((int64_t)(tile * (8 / stat_rows) + wpx) * 2) * a.Cout + co;
+                            *reinterpret_cast<float4*>(dst) = make_float4(ssum[k2][0], ssum[k2][1], ssum[k2][2], ssum[k2][3]);
+                            *reinterpret_cast<float4*>(dst + 4) = make_float4(ssum[k2][4], ssum[k2][5], ssum[k2][6], ssum[k2][7]);
+                            *reinterpret_cast<float4*>(dst + a.Cout) = make_float4(ssq[k2][0], ssq[k2][1], ssq[k2][2], ssq[k2][3]);
+                            *reinterpret_cast<float4*>(dst + a.Cout + 4) = make_float4(ssq[k2][4], ssq[k2][5], ssq[k2][6], ssq[k2][7]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) ssum[k2][r] = ssq[k2][r] = 0.f;
+                    }
+                }
+            }
+        };
+        for (int s0 = 0; s0 < nsteps; s0 += RING / 2) {
+            [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                ((s0 + Q < nsteps ? step(std::integral_constant<int, Q>{}, s0 + Q) : (void)0), ...);
+            }(std::make_integer_sequence<int, RING / 2>{});
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight packing: fp32 OIHW -> swizzled K-row images
 // ------------------------------------------------------------------------------------------------
 template <typename T>
@@ -1349,6 +1643,80 @@ static void launch_fwd_any(int dtype, int taps, const ConvArgs& a, int bn, hipSt
     }
 }
 
+// The thin-layer kernel (conv_direct_kernel) serves bf16 3x3 convolutions whose whole packed weight image fits in LDS and
+// whose input has one or two K-rows made of whole 32-channel k-substeps.  Returns false when the layer is not one of its.
+static bool launch_direct(const ConvArgs& c, int bn, hipStream_t st) {
+    static const bool off = getenv("SEGK_NO_DIRECT") != nullptr;          // experiment switch: always the LDS-staged kernels
+    if (off || c.depth > 0 || c.nb_part || c.cout_pad > 128 || c.W % kTW || c.H % 2 || c.C0 % 32 || c.C1 % 32) return false;
+    if (c.stat_part && c.H % 8) return false;
+    if (c.vin.sy != 1 || c.vin.sx != 1 || c.vout.sy != 1 || c.vout.sx != 1) return false;
+    int nk0, nk1;
+    if (c.C1 > 0) { nk0 = c.C0 / 32; nk1 = c.C1 / 32; if (nk0 > 2 || nk1 > 2) return false; }
+    else if (c.C0 <= 64) { nk0 = c.C0 / 32; nk1 = 0; }
+    else if (c.C0 <= 128) { nk0 = 2; nk1 = c.C0 / 32 - 2; }
+    else return false;
+    // 128 output channels run as two blocks of 64 (the accumulators of one 128-wide block leave no registers for rows in flight)
+    const int ncb = c.cout_pad == 128 ? 2 : 1;
+    const int ni = c.cout_pad / ncb / 16;
+    DirectArgs a;
+    a.seg0 = c.x0; a.seg1 = c.C1 > 0 ? c.x1 : nullptr;
+    a.ldb0 = c.ld0 * 2; a.ldb1 = c.ld1 * 2; a.off1 = 128;
+    a.N = c.N; a.H = c.H; a.W = c.W; a.strips_x = c.W / kTW;
+    a.w = c.w; a.Cout = c.Cout; a.bias = c.bias;
+    a.y = c.y; a.ldy = c.ldy; a.y1 = c.y1; a.ldy1 = c.ldy1; a.split = c.split; a.accumulate = c.accumulate; a.accumulate1 = c.accumulate1;
+    a.mask = c.mask; a.ld_mask = c.ld_mask; a.mask_c = c.mask_c; a.relu = c.relu;
+    a.stat_part = c.stat_part; a.tiles_x = c.tiles_x; a.tiles_y = c.tiles_y;
+    static const bool no_pairs = getenv("SEGK_DIRECT_NO_PAIRS") != nullptr;   // experiment switch
+    a.pair_first = 99;
+    if (!no_pairs) {
+        if (!c.y1 || c.split % 64 == 0) a.pair_first = 0;
+        else if (c.split % 32 == 0) a.pair_first = c.split / 32;
+    }
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    // rows per unit: a multiple of 8 (statistics rows never span units) that balances the units over the waves with the
+    // least work in the busiest one (two extra input rows per unit)
+    const int64_t waves = (int64_t)cus * kDirectWaves;
+    int best = 8;
+    int64_t best_cost = INT64_MAX;
+    for (int seg = 8; seg <= 128; seg += 8) {
+        const int64_t units = (int64_t)c.N * ncb * ((c.H + seg - 1) / seg) * a.strips_x;
+        const int64_t cost = ((units + waves - 1) / waves) * (seg + 4);
+        if (cost < best_cost) { best_cost = cost; best = seg; }
+    }
+    a.seg_rows = best; a.segs_y = (c.H + best - 1) / best;
+    const int64_t units = (int64_t)c.N * ncb * a.segs_y * a.strips_x;
+    if (units >= (1ll << 31)) return false;
+    a.units = (int)units;
+    const dim3 grid((unsigned)cus), block(64 * kDirectWaves);
+#define SEGK_DIRECT_CASE(K0, K1, I, CB, P, PS, PM, AB)                                                      \
+    if (nk0 == K0 && nk1 == K1 && ni == I && ncb == CB) {                                                     \
+        if (a.stat_part && a.mask) return false;                                                              \
+        if (a.stat_part) {                                                                                    \
+            if constexpr (PS >= 0) hipLaunchKernelGGL((conv_direct_kernel<K0, K1, I, (PS >= 0 ? PS : 1), true, false, AB, CB>), grid, block, 0, st, a); \
+            else return false;                                                                                \
+        } else if (a.mask) {                                                                                  \
+            if constexpr (PM >= 0) hipLaunchKernelGGL((conv_direct_kernel<K0, K1, I, (PM >= 0 ? PM : 1), false, true, AB, CB>), grid, block, 0, st, a); \
+            else return false;                                                                                \
+        } else hipLaunchKernelGGL((conv_direct_kernel<K0, K1, I, P, false, false, AB, CB>), grid, block, 0, st, a); \
+        return true;                                                                                          \
+    }
+    // (k-substeps of K-row 0, of K-row 1, 16-channel output tiles per block, blocks, steps of prefetch, the same with
+    // statistics and with a mask (-1: not served), weight-fragment buffers)
+    SEGK_DIRECT_CASE(2, 0, 4, 1, 2, -1, 1, 2)     // 64 -> 64 (with statistics: the LDS-staged kernel, which is faster there)
+    SEGK_DIRECT_CASE(1, 2, 2, 1, 1, 1, -1, 2)     // [32 | 64] -> 32
+    SEGK_DIRECT_CASE(2, 1, 2, 1, 1, 1, -1, 2)     // 96 -> 32 from one tensor
+    SEGK_DIRECT_CASE(1, 0, 6, 1, 3, -1, 1, 1)     // 32 -> 96   (data gradient of [32 | 64] -> 32)
+    SEGK_DIRECT_CASE(1, 0, 4, 2, 3, -1, 3, 2)     // 32 -> 128  (data gradient of 128 -> 32)
+    SEGK_DIRECT_CASE(1, 0, 4, 1, 3, 2, 3, 2)      // 32 -> 64
+    SEGK_DIRECT_CASE(1, 0, 2, 1, 3, 3, 3, 2)      // 32 -> 32
+#undef SEGK_DIRECT_CASE
+    return false;
+}
+
 static int wgrad_splits(int64_t ntiles, int64_t ncb, int64_t nch) {
     // Two workgroups fit a CU (LDS and registers), so 512 are resident at once.  Exactly one resident round has
     // no tail and keeps the partial-slab traffic (147 KB written and read back per workgroup) at its minimum;
@@ -1490,7 +1858,7 @@ static int conv_fwd_impl(int dtype, int taps, const void* x0, int64_t ld0, int64
     const int bn = pick_bn(a.cout_pad);
     SEGK_REQUIRE((int64_t)a.N * a.tiles_x * a.tiles_y * (a.cout_pad / bn) < (1ll << 31), SEGK_ESHAPE, "conv_fwd: grid too large");
     hipStream_t st = (hipStream_t)stream;
-    launch_fwd_any(dtype, taps, a, bn, st);
+    if (!(dtype == SEGK_BF16 && taps == 9 && launch_direct(a, bn, st))) launch_fwd_any(dtype, taps, a, bn, st);
     SEGK_LAUNCH_CHECK();
     return SEGK_OK;
 }

@@ -59,6 +59,8 @@ for name, H, Cin, Cout in LAYERS:
     totf += fl
     if os.environ.get("CHECK"):      # checksums of the results (compare two builds / modes on identical inputs)
         torch.cuda.synchronize()
-        line += f" sum|y| {float(y.buf.float().abs().sum()):.6e} sum|dx| {float(dx.buf.float().abs().sum()):.6e} sum|dw| {float(dw.abs().sum()):.6e}"
+        bits = lambda t: int((t.view(torch.int16).long() * (torch.arange(t.numel(), device=t.device).view(t.shape) % 251 + 1)).sum())
+        line += (f" sum|y| {float(y.buf.float().abs().sum()):.6e} sum|dx| {float(dx.buf.float().abs().sum()):.6e} sum|dw| {float(dw.abs().sum()):.6e}"
+                 f" bits(y) {bits(y.buf)} bits(dx) {bits(dx.buf)}")
     print(line, flush=True)
 print("TOTAL", {k: f"{v:.2f} ms {totf/v/1e9:.0f} TF" for k, v in tot.items()})
