@@ -65,6 +65,7 @@ struct ConvArgs {
     int depth = 0, nkd = 3;
     int64_t slice_bytes = 0;          // bytes between consecutive slices of the input
     float* stat_part = nullptr;       // optional [N*tiles][pixel-wave][2][Cout]: per-wave sum / sum of squares of the stored output
+    int stat_rpt = 0;                 // rows per tile of stat_part when the caller sized it for four (0: one per pixel-wave)
     // Data gradient whose output is the gradient of relu(norm(z)): the epilogue also produces the two sums the norm's
     // backward needs (sum g, sum g*zhat with g masked by the ReLU), rows laid out as stat_part's.
     const char* nb_z = nullptr; int64_t nb_ldz = 0;   // z: what the norm read, same pixels and channels as the output
@@ -623,11 +624,19 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
         for (int r = 0; r < 8; ++r) { ssum[r] = row16_sum(ssum[r]); ssq[r] = row16_sum(ssq[r]); }
         if (l15 == 0) {
             const int tile = (n * a.tiles_y + ty) * a.tiles_x + tx;
-            float* dst = a.stat_part + ((int64_t)(tile * WPX_WAVES + wpx) * 2) * a.Cout + co;
+            const int rpt = a.stat_rpt > WPX_WAVES ? a.stat_rpt : WPX_WAVES;
+            float* dst = a.stat_part + ((int64_t)(tile * rpt + wpx) * 2) * a.Cout + co;
             *reinterpret_cast<float4*>(dst) = make_float4(ssum[0], ssum[1], ssum[2], ssum[3]);
             *reinterpret_cast<float4*>(dst + 4) = make_float4(ssum[4], ssum[5], ssum[6], ssum[7]);
             *reinterpret_cast<float4*>(dst + a.Cout) = make_float4(ssq[0], ssq[1], ssq[2], ssq[3]);
             *reinterpret_cast<float4*>(dst + a.Cout + 4) = make_float4(ssq[4], ssq[5], ssq[6], ssq[7]);
+            // a buffer sized for more rows per tile than this variant has pixel-waves: the rows it does not own are zero
+            for (int extra = WPX_WAVES + wpx; extra < rpt; extra += WPX_WAVES) {
+                float* z = a.stat_part + ((int64_t)(tile * rpt + extra) * 2) * a.Cout + co;
+                const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(z) = zero; *reinterpret_cast<float4*>(z + 4) = zero;
+                *reinterpret_cast<float4*>(z + a.Cout) = zero; *reinterpret_cast<float4*>(z + a.Cout + 4) = zero;
+            }
         }
     }
     SEGK_PROBE_EXIT();
@@ -746,14 +755,6 @@ __global__ __launch_bounds__(64 * kDirectWaves, 2) void conv_direct_kernel(const
         [&]<int... R>(std::integer_sequence<int, R...>) { (load_row(std::integral_constant<int, R % RING>{}, R), ...); }(
             std::make_integer_sequence<int, 2 * PD + 2>{});
 
-        float ssum[STATS ? NI / 2 : 1][8], ssq[STATS ? NI / 2 : 1][8];
-        if constexpr (STATS) {
-#pragma unroll
-            for (int k2 = 0; k2 < NI / 2; ++k2)
-#pragma unroll
-                for (int r = 0; r < 8; ++r) ssum[k2][r] = ssq[k2][r] = 0.f;
-        }
-
         auto step = [&](auto q_tag, int st) {
             constexpr int q = decltype(q_tag)::value;             // position inside the unrolled group: window slots 2q .. 2q+3
             // request the rows of step st + PD
@@ -810,6 +811,13 @@ __global__ __launch_bounds__(64 * kDirectWaves, 2) void conv_direct_kernel(const
                     __builtin_amdgcn_sched_barrier(0);
                 }(), ...);
             }(std::make_integer_sequence<int, NBLK>{});
+            float ssum[STATS ? NI / 2 : 1][8], ssq[STATS ? NI / 2 : 1][8];   // this step's two rows
+            if constexpr (STATS) {
+#pragma unroll
+                for (int k2 = 0; k2 < NI / 2; ++k2)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) ssum[k2][r] = ssq[k2][r] = 0.f;
+            }
             // epilogue of the two rows: the conv_fwd_kernel epilogue for one pixel row per j.  The results are first packed to
             // bf16, then stored: a lane holds 16 bytes (8 channels) of a pixel, four lanes (g) one 64-byte half of a 64-channel
             // stretch, so one store instruction per 32-channel group writes HALF cache lines of 16 pixels.  Where two groups
@@ -892,29 +900,23 @@ __global__ __launch_bounds__(64 * kDirectWaves, 2) void conv_direct_kernel(const
                     }
                 }
             }
-            // statistics rows keep the layout of conv_fwd_kernel's (one row per 8x16 tile and group of pixel rows): a row is
-            // closed after every `stat_rows` output rows
+            // one statistics row per step: four rows per 8x16 tile, one for each pair of pixel rows (the sums live only inside
+            // the step, so that they hold no registers while rows are in flight)
             if constexpr (STATS) {
-                const int stat_rows = (BN == 64 || BN == 128) ? 4 : 2;   // rows per pixel-wave of the LDS-staged variant of this width
-                const int yy1 = ys + 2 * st + 1;
-                if ((yy1 + 1) % stat_rows == 0) {
-                    const int ty = yy1 / 8, wpx = (yy1 % 8) / stat_rows;
-                    const int tile = (n * a.tiles_y + ty) * a.tiles_x + sx;
+                const int yy0 = ys + 2 * st;
+                const int64_t row = ((int64_t)(n * a.tiles_y + yy0 / 8) * a.tiles_x + sx) * 4 + (yy0 % 8) / 2;
 #pragma unroll
-                    for (int k2 = 0; k2 < NI / 2; ++k2) {
-                        const int co = cb * BN + 32 * k2 + 8 * g;
-                        if (co >= a.Cout) continue;
+                for (int k2 = 0; k2 < NI / 2; ++k2) {
+                    const int co = cb * BN + 32 * k2 + 8 * g;
+                    if (co >= a.Cout) continue;
 #pragma unroll
-                        for (int r = 0; r < 8; ++r) { ssum[k2][r] = row16_sum(ssum[k2][r]); ssq[k2][r] = row16_sum(ssq[k2][r]); }
-                        if (l15 == 0) {
-                            float* dst = a.stat_part + ((int64_t)(tile * (8 / stat_rows) + wpx) * 2) * a.Cout + co;
-                            *reinterpret_cast<float4*>(dst) = make_float4(ssum[k2][0], ssum[k2][1], ssum[k2][2], ssum[k2][3]);
-                            *reinterpret_cast<float4*>(dst + 4) = make_float4(ssum[k2][4], ssum[k2][5], ssum[k2][6], ssum[k2][7]);
-                            *reinterpret_cast<float4*>(dst + a.Cout) = make_float4(ssq[k2][0], ssq[k2][1], ssq[k2][2], ssq[k2][3]);
-                            *reinterpret_cast<float4*>(dst + a.Cout + 4) = make_float4(ssq[k2][4], ssq[k2][5], ssq[k2][6], ssq[k2][7]);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) ssum[k2][r] = ssq[k2][r] = 0.f;
+                    for (int r = 0; r < 8; ++r) { ssum[k2][r] = row16_sum(ssum[k2][r]); ssq[k2][r] = row16_sum(ssq[k2][r]); }
+                    if (l15 == 0) {
+                        float* dst = a.stat_part + row * 2 * a.Cout + co;
+                        *reinterpret_cast<float4*>(dst) = make_float4(ssum[k2][0], ssum[k2][1], ssum[k2][2], ssum[k2][3]);
+                        *reinterpret_cast<float4*>(dst + 4) = make_float4(ssum[k2][4], ssum[k2][5], ssum[k2][6], ssum[k2][7]);
+                        *reinterpret_cast<float4*>(dst + a.Cout) = make_float4(ssq[k2][0], ssq[k2][1], ssq[k2][2], ssq[k2][3]);
+                        *reinterpret_cast<float4*>(dst + a.Cout + 4) = make_float4(ssq[k2][4], ssq[k2][5], ssq[k2][6], ssq[k2][7]);
                     }
                 }
             }
@@ -1648,7 +1650,7 @@ static void launch_fwd_any(int dtype, int taps, const ConvArgs& a, int bn, hipSt
 static bool launch_direct(const ConvArgs& c, int bn, hipStream_t st) {
     static const bool off = getenv("SEGK_NO_DIRECT") != nullptr;          // experiment switch: always the LDS-staged kernels
     if (off || c.depth > 0 || c.nb_part || c.cout_pad > 128 || c.W % kTW || c.H % 2 || c.C0 % 32 || c.C1 % 32) return false;
-    if (c.stat_part && c.H % 8) return false;
+    if (c.stat_part && (c.H % 8 || c.stat_rpt != 4)) return false;   // its statistics come one row per pair of pixel rows
     if (c.vin.sy != 1 || c.vin.sx != 1 || c.vout.sy != 1 || c.vout.sx != 1) return false;
     int nk0, nk1;
     if (c.C1 > 0) { nk0 = c.C0 / 32; nk1 = c.C1 / 32; if (nk0 > 2 || nk1 > 2) return false; }
@@ -1706,7 +1708,8 @@ static bool launch_direct(const ConvArgs& c, int bn, hipStream_t st) {
     }
     // (k-substeps of K-row 0, of K-row 1, 16-channel output tiles per block, blocks, steps of prefetch, the same with
     // statistics and with a mask (-1: not served), weight-fragment buffers)
-    SEGK_DIRECT_CASE(2, 0, 4, 1, 2, -1, 1, 2)     // 64 -> 64 (with statistics: the LDS-staged kernel, which is faster there)
+    SEGK_DIRECT_CASE(2, 0, 4, 1, 2, 2, 1, 2)      // 64 -> 64
+    SEGK_DIRECT_CASE(2, 0, 4, 2, 1, -1, -1, 2)    // 64 -> 128 (with statistics the LDS-staged kernel is as fast)
     SEGK_DIRECT_CASE(1, 2, 2, 1, 1, 1, -1, 2)     // [32 | 64] -> 32
     SEGK_DIRECT_CASE(2, 1, 2, 1, 1, 1, -1, 2)     // 96 -> 32 from one tensor
     SEGK_DIRECT_CASE(1, 0, 6, 1, 3, -1, 1, 1)     // 32 -> 96   (data gradient of [32 | 64] -> 32)
@@ -1842,6 +1845,7 @@ static int conv_fwd_impl(int dtype, int taps, const void* x0, int64_t ld0, int64
     const int kr = krow(dtype);
     ConvArgs a;
     a.stat_part = stat_partials;
+    a.stat_rpt = (flags & 8) ? 4 : 0;
     a.nb_z = (const char*)nb.z; a.nb_ldz = nb.ldz; a.nb_stats = nb.stats; a.nb_gamma = nb.gamma; a.nb_beta = nb.beta; a.nb_part = nb.partials;
     a.x0 = (const char*)x0; a.x1 = (const char*)x1; a.ld0 = ld0; a.ld1 = ld1;
     a.C0 = (int)C0; a.C1 = (int)C1;
@@ -1889,6 +1893,12 @@ extern "C" int64_t segk_conv_stat_rows(int64_t N, int64_t H, int64_t W, int64_t 
     const int bn = pick_bn(round_up(Cout, 32));
     const int wpx = (bn == 128 || bn == 64) ? 2 : 4;
     return N * ((H + 7) / 8) * ((W + kTW - 1) / kTW) * wpx;
+}
+
+// rows of the statistics buffer of a segk_conv_fwd call that sets flag bit 3: four per (image, tile) whatever the kernel
+extern "C" int64_t segk_conv_stat_rows_fine(int64_t N, int64_t H, int64_t W) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    return N * ((H + 7) / 8) * ((W + kTW - 1) / kTW) * 4;
 }
 
 extern "C" size_t segk_conv_wgrad_workspace(int dtype, int taps, int64_t C0, int64_t C1, int64_t N, int64_t H, int64_t W,

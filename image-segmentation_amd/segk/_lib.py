@@ -46,6 +46,7 @@ _PROTOS = {
     "segk_conv_pack_batch": (I, [I, P, L, L, I, P]),
     "segk_conv_fwd": (I, [I, I, P, L, L, P, L, L, L, L, L, P, L, P, P, L, P, L, L, P, L, L, P, I, I, P]),
     "segk_conv_stat_rows": (L, [L, L, L, L]),
+    "segk_conv_stat_rows_fine": (L, [L, L, L]),
     "segk_conv_dgrad_norm": (I, [I, I, P, L, L, L, L, L, P, L, P, L, P, L, P, P, P, P, I, P]),
     "segk_norm_stats_finalize_workspace": (Z, [L, L, L]),
     "segk_norm_stats_finalize": (I, [P, L, L, L, L, F, P, P, P, F, P, Z, I, P]),

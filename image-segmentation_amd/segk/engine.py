@@ -237,12 +237,14 @@ class Runtime:
         return wf, wb
 
     # ---------------------------------------------------------------- layers
-    def _stat_buffer(self, y, stats, norm_groups=None):
+    def _stat_buffer(self, y, stats, norm_groups=None, cin=None):
         """Partial-sum buffer for the convolution producing `y` when a normalisation with batch (training) or
-        instance (always) statistics follows."""
+        instance (always) statistics follows.  cin: input channels of a 3x3 convolution; thin layers (the ones the
+        weights-in-LDS kernel serves) get one row per pair of pixel rows."""
         if not stats or (norm_groups is None and not self.training) or _NO_CONV_STATS:
             return None
-        y.stat_part = ops.conv_stat_partials(y.act)
+        fine = cin is not None and self.dtype == torch.bfloat16 and cin <= 128 and y.act.C <= 128
+        y.stat_part = ops.conv_stat_partials(y.act, fine=fine)
         return y.stat_part
 
     def _norm_stats(self, y, groups, eps, stats, rmean=None, rvar=None, momentum=0.1):
@@ -370,7 +372,7 @@ class Runtime:
         y = Var(out or self.new(N, H, W, Cout), relu_fused=relu)
         xin = a0 if len(segs) == 1 else (segs[0][0], segs[1][0])
         ops.conv_fwd(xin, wf, Cout, y.act, taps=9, bias=self._bias(bname), relu=relu,
-                     stat_partials=self._stat_buffer(y, stats, norm_groups=y.act.N if stats == "instance" else None))
+                     stat_partials=self._stat_buffer(y, stats, norm_groups=y.act.N if stats == "instance" else None, cin=Cin))
 
         for name in (wname, bname):
             if name is not None:

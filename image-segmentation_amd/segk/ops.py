@@ -245,9 +245,10 @@ def _segs(x):
     return a, b
 
 
-def conv_stat_partials(out):
-    """Buffer for the per-wave output statistics of conv_fwd(..., stat_partials=...) writing `out`."""
-    rows = query("segk_conv_stat_rows", out.N, out.H, out.W, out.C)
+def conv_stat_partials(out, fine=False):
+    """Buffer for the per-wave output statistics of conv_fwd(..., stat_partials=...) writing `out`.
+    fine: four rows per (image, 8x16 tile) whatever kernel runs, which lets the weights-in-LDS kernel serve the layer."""
+    rows = query("segk_conv_stat_rows_fine", out.N, out.H, out.W) if fine else query("segk_conv_stat_rows", out.N, out.H, out.W, out.C)
     return torch.empty(rows, 2, out.C, dtype=torch.float32, device=out.device)
 
 
@@ -270,6 +271,8 @@ def conv_fwd(x, w_packed, Cout, out, taps=9, bias=None, relu=False, mask=None, a
     assert o0.C + (o1.C if o1 else 0) == Cout and (o0.N, o0.H, o0.W) == (a.N, a.H, a.W) and o0.dtype == a.dtype
     dev, st = _env(a.buf)
     flags = (RELU if relu else 0) | (ACCUM if accumulate else 0) | (4 if accumulate1 else 0)
+    if stat_partials is not None and stat_partials.shape[0] == query("segk_conv_stat_rows_fine", a.N, a.H, a.W):
+        flags |= 8                                     # four statistics rows per tile
     cin = a.C + (b.C if b else 0)
     with _Timed("conv_fwd", 2.0 * a.P * Cout * cin * taps, "128-wide" if (Cout + 31) // 32 * 32 % 128 == 0 else "narrow",
                 f"{a.H}^2 {cin}->{Cout} k{taps}"):

@@ -222,6 +222,11 @@ int segk_conv_fwd(int dtype, int taps, const void* x0, int64_t ld0, int64_t C0, 
  * InstanceNorm that follows (models/unetvgg.py:29-30,72-76; models/unetplusplus.py:11-14) without another pass over
  * y; segk_norm_stats_finalize turns them into the stats vector.  Needs one destination, no mask, no accumulation.  */
 int64_t segk_conv_stat_rows(int64_t N, int64_t H, int64_t W, int64_t Cout);
+/* flags bit3 (with stat_partials): the buffer has segk_conv_stat_rows_fine(N,H,W) rows instead -- four per (image, 8x16
+ * tile), one for each pair of pixel rows, whatever kernel runs (rows a kernel does not own are written as zeros).  Only
+ * with this layout can the thin-layer kernel, which keeps no sums across its steps, serve a layer that wants statistics;
+ * segk_norm_stats_finalize takes either layout (it only sums rows).  */
+int64_t segk_conv_stat_rows_fine(int64_t N, int64_t H, int64_t W);
 
 /* Data gradient of a convolution whose input was h = relu(batchnorm(z)) and had no other reader
  * (conv -> BatchNorm -> ReLU -> conv: models/unetvgg.py:72-76 through the VGG stages, models/unetplusplus.py:20-25):

@@ -34,7 +34,8 @@ for name, H, Cin, Cout in LAYERS:
     dx = Act.empty(N, H, H, Cin, dtype, "cuda")
     dw = torch.empty_like(w)
     fl = 2.0 * N * H * H * Cin * Cout * 9
-    fns = {"fwd": lambda: ops.conv_fwd(x, wf, Cout, y), "dgrad": lambda: ops.conv_fwd(dy, wb, Cin, dx),
+    part = ops.conv_stat_partials(y, fine=bool(os.environ.get("FINE")))
+    fns = {"fwd": lambda: ops.conv_fwd(x, wf, Cout, y), "fwds": lambda: ops.conv_fwd(x, wf, Cout, y, stat_partials=part), "dgrad": lambda: ops.conv_fwd(dy, wb, Cin, dx),
            "wgrad": lambda: ops.conv_wgrad(x, dy, dw)}
     line = f"{name:9s} {H:3d}^2 {Cin:3d}->{Cout:3d} {fl/1e9:7.1f} GF |"
     for k in which:
@@ -62,5 +63,7 @@ for name, H, Cin, Cout in LAYERS:
         bits = lambda t: int((t.view(torch.int16).long() * (torch.arange(t.numel(), device=t.device).view(t.shape) % 251 + 1)).sum())
         line += (f" sum|y| {float(y.buf.float().abs().sum()):.6e} sum|dx| {float(dx.buf.float().abs().sum()):.6e} sum|dw| {float(dw.abs().sum()):.6e}"
                  f" bits(y) {bits(y.buf)} bits(dx) {bits(dx.buf)}")
+        if "fwds" in which:
+            line += f" stat sums {float(part[:, 0].double().sum()):.9e} {float(part[:, 1].double().sum()):.9e} {float(part[:, 1].double().sum(0).max()):.9e}"
     print(line, flush=True)
 print("TOTAL", {k: f"{v:.2f} ms {totf/v/1e9:.0f} TF" for k, v in tot.items()})

@@ -584,12 +584,14 @@ def test_copy_slice_and_adam():
 
 
 @pytest.mark.parametrize("dtype", DTYPES, ids=["f32", "bf16"])
-@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 9), (3, 20, 24, 128, 96, 9), (2, 12, 40, 32, 128, 9), (1, 9, 17, 64, 32, 9), (2, 16, 16, 32, 64, 1)],
+@pytest.mark.parametrize("fine", [False, True], ids=["rows-per-wave", "four-rows-per-tile"])
+@pytest.mark.parametrize("case", [(2, 16, 16, 64, 64, 9), (3, 20, 24, 128, 96, 9), (2, 12, 40, 32, 128, 9), (1, 9, 17, 64, 32, 9), (2, 16, 16, 32, 64, 1),
+                                  (3, 24, 32, 64, 64, 9), (2, 40, 16, 32, 32, 9), (2, 16, 48, 96, 32, 9), (2, 8, 16, 32, 64, 9), (2, 16, 32, 64, 128, 9)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_conv_epilogue_statistics(dtype, case):
+def test_conv_epilogue_statistics(dtype, case, fine):
     """Per-channel statistics produced by the convolution's epilogue (partial tiles, every channel-block width, 1x1
-    taps) equal the statistics pass over the stored output, for batch (1 group) and instance (N groups) norms,
-    including the running-buffer update."""
+    taps, the thin layers of the weights-in-LDS kernel, both row layouts of the partial buffer) equal the statistics pass
+    over the stored output, for batch (1 group) and instance (N groups) norms, including the running-buffer update."""
     from segk import ops
     N, H, W, Cin, Cout, taps = case
     k = 3 if taps == 9 else 1
@@ -599,7 +601,7 @@ def test_conv_epilogue_statistics(dtype, case):
     xa = to_act(x, dtype)
     wf, _ = ops.conv_pack(w.cuda(), dtype, want_bwd=False)
     out = ops.Act(torch.zeros(N, H, W, Cout + 8, dtype=dtype, device="cuda"), 8, Cout)
-    part = ops.conv_stat_partials(out)
+    part = ops.conv_stat_partials(out, fine=fine)
     part.fill_(float("nan"))                                   # every row must be written
     ops.conv_fwd(xa, wf, Cout, out, taps=taps, bias=b.cuda(), stat_partials=part)
     assert torch.isfinite(part).all()
