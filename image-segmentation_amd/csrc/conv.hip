@@ -281,25 +281,30 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 #pragma unroll
     for (int part = 0; part < HPARTS; ++part) stage_halo_part(0, 0, part);
     stage_w(0, 0);
-    // Norm-backward sums (see the epilogue): the wave's vectors of z.  The skewed-loop kernel has the registers to request
-    // them here, where the wait for the first halo covers their latency; the other variants load them in the epilogue.
+    // Vectors the epilogue needs besides the accumulators, one per (channel pair tile, pixel row) of the wave: z for the
+    // norm-backward sums, or the ReLU mask of a data gradient.  The skewed-loop kernel has the registers to request them
+    // here, where the wait for the first halo covers their latency; the other variants request all of them at the start of
+    // the epilogue (one latency instead of one per vector).
     struct alignas(16) Pack8 { T e[8]; };
     constexpr bool kEarlyZ = PIPE;
     Pack8 zr[NI / 2][NJ];
-    auto load_z = [&]() {
+    auto load_side = [&](const char* base, int64_t ld, int cmax) {
 #pragma unroll
         for (int k2 = 0; k2 < NI / 2; ++k2) {
             const int co = cb * BN + (wave / WPX_WAVES) * WCO + 32 * k2 + 8 * (lane >> 4);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int yy = y0 + (wave % WPX_WAVES) * NJ + j, xx = x0 + (lane & 15);
-                if (co < a.Cout && yy < a.H && xx < a.W)
-                    zr[k2][j] = *reinterpret_cast<const Pack8*>(reinterpret_cast<const T*>(a.nb_z) + (int64_t)a.vout.pixel(n, yy, xx) * a.nb_ldz + co);
+                if (co < cmax && yy < a.H && xx < a.W)
+                    zr[k2][j] = *reinterpret_cast<const Pack8*>(reinterpret_cast<const T*>(base) + (int64_t)a.vout.pixel(n, yy, xx) * ld + co);
             }
         }
     };
+    auto load_z = [&]() { load_side(a.nb_z, a.nb_ldz, a.Cout); };
+    auto load_mask = [&]() { load_side(a.mask, a.ld_mask, a.mask_c); };
     if constexpr (kEarlyZ) {
         if (a.nb_part) load_z();
+        else if (a.mask) load_mask();
     }
     dma_wait_all();
     __syncthreads();
@@ -545,6 +550,18 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
         return;
     }
     if (!a.stat_part) {
+        if constexpr (!kEarlyZ) {
+            if (a.mask) load_mask();
+        }
+        // the bias of the wave's channels, requested once (a load between the stores of two rows would wait for memory again)
+        float bv[NI / 2][8];
+#pragma unroll
+        for (int k2 = 0; k2 < NI / 2; ++k2) {
+            const int co = cb * BN + wco * WCO + 32 * k2 + 8 * g;
+            float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+            if (a.bias && co < a.Cout) { b0 = *reinterpret_cast<const float4*>(a.bias + co); b1 = *reinterpret_cast<const float4*>(a.bias + co + 4); }
+            bv[k2][0] = b0.x; bv[k2][1] = b0.y; bv[k2][2] = b0.z; bv[k2][3] = b0.w; bv[k2][4] = b1.x; bv[k2][5] = b1.y; bv[k2][6] = b1.z; bv[k2][7] = b1.w;
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int yy = y0 + wpx * NJ + j, xx = x0 + l15;
@@ -558,18 +575,16 @@ __global__ __launch_bounds__(64 * WPX_WAVES * WCO_WAVES, WGS * 256 / (64 * WPX_W
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e]; v[4 + e] = acc[2 * k2 + 1][j][e]; }
                 if (a.bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) v[r] += bv[k2][r];
                 }
                 if (a.relu) {
 #pragma unroll
                     for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
                 if (a.mask && co < a.mask_c) {
-                    float m[8];
-                    Elem<T>::load8(reinterpret_cast<const T*>(a.mask) + pix * a.ld_mask + co, m);
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
+                    for (int r = 0; r < 8; ++r) v[r] = Elem<T>::to_f(zr[k2][j].e[r]) > 0.f ? v[r] : 0.f;
                 }
                 const bool second = co >= a.split;
                 T* dst = second ? reinterpret_cast<T*>(a.y1) + pix * a.ldy1 + (co - a.split) : reinterpret_cast<T*>(a.y) + pix * a.ldy + co;
@@ -687,11 +702,15 @@ __global__ __launch_bounds__(64 * kDirectWaves, 2) void conv_direct_kernel(const
     constexpr int WBYTES = NCH * 9 * NCB * BN * kRowBytes;
     static_assert(NI % 2 == 0 && WBYTES <= 150 * 1024, "weight image must fit in LDS");
     __shared__ __attribute__((aligned(16))) char sw[WBYTES];
+    __shared__ __attribute__((aligned(16))) float sbias[NCB * BN];   // the bias beside the weights: an epilogue that waited on
+                                                                     // global memory for it would stall every step
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, l15 = lane & 15;
     for (int q = tid; q < WBYTES / 16; q += 64 * kDirectWaves)
         *reinterpret_cast<Slot*>(sw + q * 16) = *reinterpret_cast<const Slot*>(a.w + (int64_t)q * 16);
+    if (a.bias)
+        for (int q = tid; q < NCB * BN; q += 64 * kDirectWaves) sbias[q] = q < a.Cout ? a.bias[q] : 0.f;
     __syncthreads();
 
     // per k-substep: segment base, pixel stride and byte offset of this lane's 16 bytes inside a pixel
@@ -836,8 +855,8 @@ __global__ __launch_bounds__(64 * kDirectWaves, 2) void conv_direct_kernel(const
                     float v[8];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { v[e] = acc[2 * k2][j][e]; v[4 + e] = acc[2 * k2 + 1][j][e]; }
-                    if (a.bias && co < a.Cout) {
-                        const float4 b0 = *reinterpret_cast<const float4*>(a.bias + co), b1 = *reinterpret_cast<const float4*>(a.bias + co + 4);
+                    if (a.bias) {
+                        const float4 b0 = *reinterpret_cast<const float4*>(sbias + co), b1 = *reinterpret_cast<const float4*>(sbias + co + 4);
                         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                     }
                     if (a.relu) {

@@ -35,7 +35,8 @@ for name, H, Cin, Cout in LAYERS:
     dw = torch.empty_like(w)
     fl = 2.0 * N * H * H * Cin * Cout * 9
     part = ops.conv_stat_partials(y, fine=bool(os.environ.get("FINE")))
-    fns = {"fwd": lambda: ops.conv_fwd(x, wf, Cout, y), "fwds": lambda: ops.conv_fwd(x, wf, Cout, y, stat_partials=part), "dgrad": lambda: ops.conv_fwd(dy, wb, Cin, dx),
+    bias = torch.randn(Cout, device="cuda") if os.environ.get("BIAS") else None
+    fns = {"fwd": lambda: ops.conv_fwd(x, wf, Cout, y, bias=bias), "fwds": lambda: ops.conv_fwd(x, wf, Cout, y, bias=bias, stat_partials=part), "dgrad": lambda: ops.conv_fwd(dy, wb, Cin, dx, mask=x if os.environ.get("MASK") else None),
            "wgrad": lambda: ops.conv_wgrad(x, dy, dw)}
     line = f"{name:9s} {H:3d}^2 {Cin:3d}->{Cout:3d} {fl/1e9:7.1f} GF |"
     for k in which:

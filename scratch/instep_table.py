@@ -29,7 +29,7 @@ def short(name):
 def is_conv(name):
     if "conv_wgrad_reduce" in name or "conv_first_wgrad_reduce" in name or "conv_pack" in name:
         return None
-    if "conv_fwd_kernel" in name and "conv_first" not in name:
+    if ("conv_fwd_kernel" in name or "conv_direct_kernel" in name) and "conv_first" not in name:
         return "conv_fwd"
     if "conv_wgrad_kernel" in name and "conv_first" not in name:
         return "conv_wgrad"
