@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-wgrad-stream", action="store_true",
                     help="keep the weight gradients on the main stream (default: on a second HIP stream next to the data gradients, "
-                         "except on the steps whose launches are event-timed and with more than one rank)")
+                         "for every rank count; the steps whose launches are event-timed keep everything on one stream)")
     ap.add_argument("--bucket-mb", type=float, default=25.0,
                     help="size of the flat gradient buckets that are all-reduced one by one while the backward pass is still running")
     ap.add_argument("--launch-table", default=None,
@@ -485,7 +485,7 @@ def main():
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             # HBM bytes of the same launches (one step) from the committed PMC passes of this workload (counters cannot be read
             # from inside this process): reported only while the kernel sources are the ones the passes were taken on
-            traffic, traffic_note = None, None
+            traffic, traffic_note = None, "no PMC passes are committed for this workload"
             tfile = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
             if args.model == "unetvgg" and args.dtype == "bf16" and args.batch == 32 and args.side == 384 and os.path.exists(tfile):  # noqa: E501
                 with open(tfile) as f:

@@ -39,7 +39,7 @@ for name in sorted(fetch, key=lambda k: -sum(fetch[k]) * 2 - sum(write.get(k, []
     total += rd + wr
     # what bench.py times as convolution; the statistics-only and sums passes of the fused first layer stand in for BatchNorm passes
     norm_pass = re.search(r"conv_first_fwd_kernel<\d+, \d+, 1>|conv_first_wgrad_kernel<\d+, 1>", name) is not None
-    if any(k in name for k in ("conv_fwd_kernel", "conv_wgrad_kernel", "conv_wgrad_reduce_kernel", "conv_first_")) and not norm_pass:
+    if any(k in name for k in ("conv_fwd_kernel", "conv_direct_kernel", "conv_wgrad_kernel", "conv_wgrad_reduce", "conv_first_")) and not norm_pass:
         conv += rd + wr
     kernels[name] = {"launches_per_step": round(n / steps, 2), "hbm_read_bytes_per_launch": int(rd / n),
                      "hbm_write_bytes_per_launch": int(wr / n)}
